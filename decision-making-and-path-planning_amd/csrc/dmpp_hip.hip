@@ -1,0 +1,610 @@
+// dmpp_hip.hip — the C-ABI of include/dmpp_planner.h over the HIP kernels (gfx950 only).
+//
+// One handle = one device, one stream, all device buffers.  pp_plan_tick enqueues, in order:
+//   k_effective_obstacles -> k_decision -> k_planning -> k_rasterise -> k_search -> k_score
+// Nothing here computes planning results on the host; without a GPU pp_create fails.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+#include "../../include/dmpp_planner.h"
+#include "kernels_r.hpp"
+#include "kernels_g.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail(PP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
+    } while (0)
+
+struct EvPair { hipEvent_t a, b; int k; };
+
+}  // namespace
+
+struct pp_planner {
+    PlannerConfig cfg;
+    PlannerCaps caps;
+    int device = 0;
+    int n_scenes = 0;
+    hipStream_t stream = nullptr;
+    // inputs
+    SceneIn* d_in = nullptr; GlobalPoint3D* d_lane = nullptr; GlobalPoint2D* d_ref = nullptr;
+    ObPoint* d_obs = nullptr; ObMotion* d_mot = nullptr; ObPoint* d_obs_now = nullptr;
+    bool have_motion = false;
+    // state / outputs
+    SceneState* d_state = nullptr; PlanOut* d_plan = nullptr; GridOut* d_gout = nullptr;
+    GlobalPoint2D* d_dec_ref = nullptr;
+    // grid engine
+    uint8_t* d_grid = nullptr; uint8_t* d_parent = nullptr; uint32_t* d_bucket = nullptr;
+    int32_t* d_order = nullptr; int32_t* d_path = nullptr; uint32_t* d_gbm = nullptr;
+    size_t grid_cells = 0;       // per scene, at creation
+    int bucket_cap0 = 0, max_path0 = 0;
+    bool search_gbm = false; int search_lds = 0; int raster_band_rows = 0;
+    // op scratch (stand-alone operators)
+    void* d_scratch = nullptr; size_t scratch_bytes = 0;
+    // profiling
+    bool profile = false;
+    std::vector<EvPair> pending; std::vector<hipEvent_t> free_events;
+    float k_ms[PP_K_COUNT] = {0}; int k_launches[PP_K_COUNT] = {0};
+};
+
+namespace {
+
+template <class T> int dmalloc(T** p, size_t count)
+{
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return PP_OK;
+}
+
+int check_cfg(const PlannerConfig* c)
+{
+    if (!c) return fail(PP_ERR_ARG, "config is null");
+    if (c->grid_stage) {
+        if (c->grid_w <= 0 || c->grid_h <= 0 || (c->grid_w % 32) != 0) return fail(PP_ERR_ARG, "grid_w must be a positive multiple of 32");
+        if ((long long)c->grid_w * c->grid_h > (1ll << 24)) return fail(PP_ERR_ARG, "grid larger than 2^24 cells (cell index is 24 bits in an open-set entry)");
+        if (c->bucket_cap < 64 || c->max_path < 2) return fail(PP_ERR_ARG, "bucket_cap/max_path too small");
+        if ((long long)16 * c->bucket_cap < c->max_path) return fail(PP_ERR_ARG, "16*bucket_cap must be >= max_path");
+        if (!(c->cell > 0)) return fail(PP_ERR_ARG, "cell size must be positive");
+        if (c->n_lattice < 0 || c->n_lattice > DMPP_MAX_LATTICE - 1) return fail(PP_ERR_ARG, "n_lattice out of range");
+    }
+    return PP_OK;
+}
+
+hipEvent_t get_event(pp_planner* h)
+{
+    if (!h->free_events.empty()) { hipEvent_t e = h->free_events.back(); h->free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct Timed {
+    pp_planner* h; int k; hipEvent_t a = nullptr, b = nullptr;
+    Timed(pp_planner* h_, int k_) : h(h_), k(k_) {
+        if (h->profile) { a = get_event(h); b = get_event(h); if (a) (void)hipEventRecord(a, h->stream); }
+    }
+    ~Timed() {
+        if (h->profile && a && b) { (void)hipEventRecord(b, h->stream); h->pending.push_back({a, b, k}); }
+    }
+};
+
+int drain_events(pp_planner* h)
+{
+    if (h->pending.empty()) return PP_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto& p : h->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { h->k_ms[p.k] += ms; h->k_launches[p.k] += 1; }
+        h->free_events.push_back(p.a); h->free_events.push_back(p.b);
+    }
+    h->pending.clear();
+    return PP_OK;
+}
+
+int setup_grid_launch(pp_planner* h)
+{
+    const PlannerConfig& c = h->cfg;
+    if (!c.grid_stage) return PP_OK;
+    const size_t N = (size_t)c.grid_w * c.grid_h;
+    // rasterise: bands of <= 65536 cells (8 KiB of LDS bits), whole rows
+    int band = 65536 / c.grid_w; if (band < 1) band = 1; if (band > c.grid_h) band = c.grid_h;
+    h->raster_band_rows = band;
+    // search: bitmap in LDS when it fits next to nothing else, else in HBM
+    const size_t bm_bytes = N / 8;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    const size_t lds_max = prop.sharedMemPerBlock;        // 64 KiB default, 160 KiB opt-in on gfx950
+    size_t optin = lds_max;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && v > 0) optin = (size_t)v;
+    }
+    h->search_gbm = bm_bytes + 256 > (optin > lds_max ? optin : lds_max) || bm_bytes > 160u * 1024u - 256u;
+    h->search_lds = h->search_gbm ? 0 : (int)bm_bytes;
+    if (!h->search_gbm && bm_bytes > 48u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_search<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); h->search_gbm = true; h->search_lds = 0; }
+    }
+    if (h->search_gbm && !h->d_gbm) {
+        int r = dmalloc(&h->d_gbm, (size_t)h->caps.max_scenes * (h->grid_cells / 32));
+        if (r) return r;
+    }
+    return PP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pp_last_error(void) { return g_err.c_str(); }
+
+int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_handle* out)
+{
+    if (!out || !caps) return fail(PP_ERR_ARG, "null argument");
+    *out = nullptr;
+    int r = check_cfg(cfg); if (r) return r;
+    if (caps->max_scenes <= 0) return fail(PP_ERR_ARG, "max_scenes must be positive");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(PP_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(PP_ERR_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    pp_planner* h = new (std::nothrow) pp_planner();
+    if (!h) return fail(PP_ERR_HIP, "out of host memory");
+    h->cfg = *cfg; h->caps = *caps; h->device = device;
+    auto bail = [&](int code) { pp_destroy(h); return code; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    const size_t ns = (size_t)caps->max_scenes;
+    if ((r = dmalloc(&h->d_in, ns))) return bail(r);
+    if ((r = dmalloc(&h->d_lane, (size_t)caps->max_lane_pts_total))) return bail(r);
+    if ((r = dmalloc(&h->d_ref, (size_t)caps->max_ref_pts_total))) return bail(r);
+    if ((r = dmalloc(&h->d_obs, (size_t)caps->max_obs_total))) return bail(r);
+    if ((r = dmalloc(&h->d_mot, (size_t)caps->max_obs_total))) return bail(r);
+    if ((r = dmalloc(&h->d_obs_now, (size_t)caps->max_obs_total))) return bail(r);
+    if ((r = dmalloc(&h->d_state, ns))) return bail(r);
+    if ((r = dmalloc(&h->d_plan, ns))) return bail(r);
+    if ((r = dmalloc(&h->d_gout, ns))) return bail(r);
+    if ((r = dmalloc(&h->d_dec_ref, ns * DMPP_MAX_REFPATH))) return bail(r);
+    if (hipMemsetAsync(h->d_gout, 0, ns * sizeof(GridOut), h->stream) != hipSuccess) return bail(fail(PP_ERR_HIP, "memset failed"));
+    if (cfg->grid_stage) {
+        h->grid_cells = (size_t)cfg->grid_w * cfg->grid_h;
+        h->bucket_cap0 = cfg->bucket_cap; h->max_path0 = cfg->max_path;
+        if ((r = dmalloc(&h->d_grid, ns * h->grid_cells))) return bail(r);
+        if ((r = dmalloc(&h->d_parent, ns * h->grid_cells))) return bail(r);
+        if ((r = dmalloc(&h->d_bucket, ns * 16 * (size_t)cfg->bucket_cap))) return bail(r);
+        if ((r = dmalloc(&h->d_path, ns * (size_t)cfg->max_path))) return bail(r);
+        if (caps->order_cap > 0 && (r = dmalloc(&h->d_order, ns * (size_t)caps->order_cap))) return bail(r);
+        if ((r = setup_grid_launch(h))) return bail(r);
+    }
+    h->scratch_bytes = 4u << 20;
+    if (hipMalloc(&h->d_scratch, h->scratch_bytes) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipMalloc(scratch) failed"));
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(PP_ERR_HIP, "sync failed"));
+    *out = h;
+    return PP_OK;
+}
+
+int pp_destroy(pp_handle h)
+{
+    if (!h) return PP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : h->free_events) (void)hipEventDestroy(e);
+    void* bufs[] = { h->d_in, h->d_lane, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now, h->d_state, h->d_plan, h->d_gout,
+                     h->d_dec_ref, h->d_grid, h->d_parent, h->d_bucket, h->d_order, h->d_path, h->d_gbm, h->d_scratch };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PP_OK;
+}
+
+int pp_set_config(pp_handle h, const PlannerConfig* cfg)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    int r = check_cfg(cfg); if (r) return r;
+    if (cfg->grid_stage) {
+        if (!h->d_grid) return fail(PP_ERR_STATE, "handle was created without the grid stage");
+        if ((size_t)cfg->grid_w * cfg->grid_h > h->grid_cells || cfg->bucket_cap > h->bucket_cap0 || cfg->max_path > h->max_path0)
+            return fail(PP_ERR_CAPACITY, "grid size / bucket_cap / max_path may not grow after pp_create");
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    h->cfg = *cfg;
+    return setup_grid_launch(h);
+}
+
+int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoint3D* lane_pool, int n_lane_pts,
+                  const GlobalPoint2D* ref_pool, int n_ref_pts, const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total)
+{
+    if (!h || !in) return fail(PP_ERR_ARG, "null argument");
+    if (n_scenes < 0 || n_scenes > h->caps.max_scenes) return fail(PP_ERR_CAPACITY, "n_scenes exceeds caps.max_scenes");
+    if (n_lane_pts > h->caps.max_lane_pts_total || n_ref_pts > h->caps.max_ref_pts_total || n_obs_total > h->caps.max_obs_total)
+        return fail(PP_ERR_CAPACITY, "pool larger than the capacity given to pp_create");
+    if (n_lane_pts < 0 || n_ref_pts < 0 || n_obs_total < 0) return fail(PP_ERR_ARG, "negative size");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d_in, in, (size_t)n_scenes * sizeof(SceneIn), hipMemcpyDefault, h->stream));
+    if (n_lane_pts && lane_pool) HIP_TRY(hipMemcpyAsync(h->d_lane, lane_pool, (size_t)n_lane_pts * sizeof(GlobalPoint3D), hipMemcpyDefault, h->stream));
+    if (n_ref_pts && ref_pool) HIP_TRY(hipMemcpyAsync(h->d_ref, ref_pool, (size_t)n_ref_pts * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    if (n_obs_total && obs_pool) HIP_TRY(hipMemcpyAsync(h->d_obs, obs_pool, (size_t)n_obs_total * sizeof(ObPoint), hipMemcpyDefault, h->stream));
+    h->have_motion = false;
+    if (n_obs_total && mot_pool) {
+        HIP_TRY(hipMemcpyAsync(h->d_mot, mot_pool, (size_t)n_obs_total * sizeof(ObMotion), hipMemcpyDefault, h->stream));
+        h->have_motion = true;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));     // the caller may reuse its buffers
+    h->n_scenes = n_scenes;
+    return PP_OK;
+}
+
+int pp_set_n_scenes(pp_handle h, int n_scenes)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    if (n_scenes < 0 || n_scenes > h->caps.max_scenes) return fail(PP_ERR_CAPACITY, "n_scenes exceeds caps.max_scenes");
+    h->n_scenes = n_scenes; h->have_motion = true;
+    return PP_OK;
+}
+
+int pp_set_state(pp_handle h, const SceneState* state, int n)
+{
+    if (!h || !state) return fail(PP_ERR_ARG, "null argument");
+    if (n < 0 || n > h->caps.max_scenes) return fail(PP_ERR_CAPACITY, "n exceeds caps.max_scenes");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d_state, state, (size_t)n * sizeof(SceneState), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PP_OK;
+}
+
+int pp_plan_tick(pp_handle h)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    const int n = h->n_scenes;
+    if (n <= 0) return PP_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const PlannerConfig& c = h->cfg;
+    {
+        Timed t(h, PP_K_OBSTACLES);
+        hipLaunchKernelGGL(dmpp::k_effective_obstacles, dim3(n), dim3(dmpp::kBlock), 0, h->stream, c, n, h->d_in, h->d_state,
+                           h->d_obs, h->have_motion ? h->d_mot : nullptr, h->d_obs_now);
+    }
+    if (c.decision_stage) {
+        Timed t(h, PP_K_DECISION);
+        hipLaunchKernelGGL(dmpp::k_decision, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::DecShared), h->stream, c, n, h->d_in, h->d_lane,
+                           h->d_ref, h->d_obs_now, h->d_state, h->d_plan, h->d_dec_ref);
+    }
+    {
+        Timed t(h, PP_K_PLANNING);
+        hipLaunchKernelGGL(dmpp::k_planning, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::PlanShared), h->stream, c, n, h->d_in, h->d_lane,
+                           h->d_ref, h->d_dec_ref, h->d_obs_now, h->d_state, h->d_plan);
+    }
+    if (c.grid_stage) {
+        {
+            Timed t(h, PP_K_RASTERISE);
+            const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
+            const size_t lds = (size_t)h->raster_band_rows * c.grid_w / 8;
+            hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, h->stream, c, n, h->raster_band_rows,
+                               h->d_in, h->d_obs_now, h->d_grid);
+        }
+        {
+            Timed t(h, PP_K_SEARCH);
+            if (h->search_gbm)
+                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), 0, h->stream, c, n, h->caps.order_cap, h->d_in, h->d_grid,
+                                   h->d_bucket, h->d_parent, h->d_order, h->d_path, h->d_gout, h->d_gbm);
+            else
+                hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap,
+                                   h->d_in, h->d_grid, h->d_bucket, h->d_parent, h->d_order, h->d_path, h->d_gout, (uint32_t*)nullptr);
+        }
+        {
+            Timed t(h, PP_K_SCORE);
+            hipLaunchKernelGGL(dmpp::k_score, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::ScoreShared), h->stream, c, n, h->d_in, h->d_obs_now,
+                               h->d_path, h->d_gout);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return PP_OK;
+}
+
+int pp_sync(pp_handle h)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PP_OK;
+}
+
+static int fetch(pp_handle h, void* dst, const void* src, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PP_OK;
+}
+
+int pp_get_plan(pp_handle h, PlanOut* out, int n)
+{
+    if (!h || !out) return fail(PP_ERR_ARG, "null argument");
+    if (n < 0 || n > h->n_scenes) return fail(PP_ERR_ARG, "n exceeds the resident scenes");
+    return fetch(h, out, h->d_plan, (size_t)n * sizeof(PlanOut));
+}
+int pp_get_state(pp_handle h, SceneState* st, int n)
+{
+    if (!h || !st) return fail(PP_ERR_ARG, "null argument");
+    if (n < 0 || n > h->caps.max_scenes) return fail(PP_ERR_ARG, "n exceeds capacity");
+    return fetch(h, st, h->d_state, (size_t)n * sizeof(SceneState));
+}
+int pp_get_grid_out(pp_handle h, GridOut* out, int n)
+{
+    if (!h || !out) return fail(PP_ERR_ARG, "null argument");
+    if (n < 0 || n > h->n_scenes) return fail(PP_ERR_ARG, "n exceeds the resident scenes");
+    return fetch(h, out, h->d_gout, (size_t)n * sizeof(GridOut));
+}
+int pp_get_grid(pp_handle h, int scene, uint8_t* grid)
+{
+    if (!h || !grid || !h->d_grid) return fail(PP_ERR_ARG, "no grid");
+    if (scene < 0 || scene >= h->n_scenes) return fail(PP_ERR_ARG, "scene out of range");
+    const size_t N = (size_t)h->cfg.grid_w * h->cfg.grid_h;
+    return fetch(h, grid, h->d_grid + (size_t)scene * N, N);
+}
+int pp_get_order(pp_handle h, int scene, int32_t* order, int cap)
+{
+    if (!h || !order || !h->d_order) return fail(PP_ERR_STATE, "expansion order was not requested (caps.order_cap == 0)");
+    if (scene < 0 || scene >= h->n_scenes) return fail(PP_ERR_ARG, "scene out of range");
+    if (cap > h->caps.order_cap) cap = h->caps.order_cap;
+    return fetch(h, order, h->d_order + (size_t)scene * h->caps.order_cap, (size_t)cap * sizeof(int32_t));
+}
+int pp_get_path(pp_handle h, int scene, int32_t* path, int cap)
+{
+    if (!h || !path || !h->d_path) return fail(PP_ERR_ARG, "no path buffer");
+    if (scene < 0 || scene >= h->n_scenes) return fail(PP_ERR_ARG, "scene out of range");
+    if (cap > h->cfg.max_path) cap = h->cfg.max_path;
+    return fetch(h, path, h->d_path + (size_t)scene * h->cfg.max_path, (size_t)cap * sizeof(int32_t));
+}
+
+int pp_plan_tick_batch(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total,
+                       const GlobalPoint3D* lane_pool, int n_lane_pts, const GlobalPoint2D* ref_pool, int n_ref_pts,
+                       SceneState* state_inout, PlanOut* out, GridOut* grid_out)
+{
+    if (!h || !state_inout || !out) return fail(PP_ERR_ARG, "null argument");
+    int r;
+    if ((r = pp_set_scenes(h, n_scenes, in, lane_pool, n_lane_pts, ref_pool, n_ref_pts, obs_pool, mot_pool, n_obs_total))) return r;
+    if ((r = pp_set_state(h, state_inout, n_scenes))) return r;
+    if ((r = pp_plan_tick(h))) return r;
+    if ((r = pp_get_plan(h, out, n_scenes))) return r;
+    if ((r = pp_get_state(h, state_inout, n_scenes))) return r;
+    if (grid_out && h->cfg.grid_stage && (r = pp_get_grid_out(h, grid_out, n_scenes))) return r;
+    return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// stand-alone operators
+}  // extern "C"
+
+namespace dmpp {
+
+constexpr int kSoMaxPts = 2048;
+
+__global__ void __launch_bounds__(DMPP_WAVE)
+k_search_obstacle_batch(PlannerConfig c, int nq, const GlobalPoint2D* __restrict__ paths, const int32_t* __restrict__ path_off,
+                        const ObPoint* __restrict__ obs, const int32_t* __restrict__ obs_off, const double* __restrict__ lo,
+                        const double* __restrict__ hi, Path_Obs* __restrict__ out)
+{
+    __shared__ double s[kSoMaxPts];
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    const int lane = threadIdx.x;
+    const int p0 = path_off[q], n = path_off[q + 1] - p0, o0 = obs_off[q], m = obs_off[q + 1] - o0;
+    SoResult r = wave_search_obstacle(c, paths + p0, n, s, obs + o0, m, lo[q], hi[q], lane);
+    if (lane == 0) store_path_obs(&out[q], r, obs + o0, true);
+}
+
+__global__ void k_geom_batch(PlannerConfig c, int op, int n, const GlobalPoint2D* a, const GlobalPoint2D* b, const GlobalPoint2D* cc, double* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (op == 0) out[i] = GetLatDis(c, a[i], b[i], cc[i]);
+    else if (op == 1) out[i] = GetRoadAngle(c, a[i], b[i]);
+    else out[i] = GetAngleErr(a[i].x, a[i].y);
+}
+
+__global__ void k_bezier(PlannerConfig c, GlobalPoint3D s, GlobalPoint3D e, GlobalPoint2D* out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Bezier bz = bezier_setup(c, s, e);
+    out[i] = bezier_point(bz, i, n);
+}
+
+__global__ void __launch_bounds__(DMPP_WAVE)
+k_cumlen(const GlobalPoint2D* in, int n, double* cum) { wave_cumlen(in, n, cum, threadIdx.x); }
+
+__global__ void k_mean_points(PlannerConfig c, const GlobalPoint2D* in, const double* cum, int n_in, GlobalPoint2D* out, int n_out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_out) out[k] = mean_point(c, in, cum, n_in, k, n_out);
+}
+
+__global__ void k_create_new_path(PlannerConfig c, const GlobalPoint2D* path, int n, double offset, GlobalPoint2D* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = offset_point(c, path, n, i, offset);
+}
+
+}  // namespace dmpp
+
+extern "C" {
+
+static int need_scratch(pp_handle h, size_t bytes)
+{
+    if (bytes <= h->scratch_bytes) return PP_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_scratch) HIP_TRY(hipFree(h->d_scratch));
+    h->d_scratch = nullptr; h->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&h->d_scratch, bytes));
+    h->scratch_bytes = bytes;
+    return PP_OK;
+}
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int pp_search_obstacle_batch(pp_handle h, int nq, const GlobalPoint2D* paths, const int32_t* path_off, const ObPoint* obs,
+                             const int32_t* obs_off, const double* lat_lo, const double* lat_hi, Path_Obs* out)
+{
+    if (!h || !paths || !path_off || !obs_off || !lat_lo || !lat_hi || !out) return fail(PP_ERR_ARG, "null argument");
+    if (nq <= 0) return PP_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    // offsets are small host arrays by contract here (they size the copies)
+    const int np = path_off[nq], no = obs_off[nq];
+    for (int q = 0; q < nq; q++) if (path_off[q + 1] - path_off[q] > dmpp::kSoMaxPts) return fail(PP_ERR_CAPACITY, "a path longer than 2048 points");
+    size_t o_paths = 0, o_poff = o_paths + al256((size_t)np * sizeof(GlobalPoint2D)), o_obs = o_poff + al256((size_t)(nq + 1) * 4),
+           o_ooff = o_obs + al256((size_t)no * sizeof(ObPoint)), o_lo = o_ooff + al256((size_t)(nq + 1) * 4),
+           o_hi = o_lo + al256((size_t)nq * 8), o_out = o_hi + al256((size_t)nq * 8), total = o_out + al256((size_t)nq * sizeof(Path_Obs));
+    int r = need_scratch(h, total); if (r) return r;
+    char* d = (char*)h->d_scratch;
+    if (np) HIP_TRY(hipMemcpyAsync(d + o_paths, paths, (size_t)np * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipMemcpyAsync(d + o_poff, path_off, (size_t)(nq + 1) * 4, hipMemcpyDefault, h->stream));
+    if (no && obs) HIP_TRY(hipMemcpyAsync(d + o_obs, obs, (size_t)no * sizeof(ObPoint), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipMemcpyAsync(d + o_ooff, obs_off, (size_t)(nq + 1) * 4, hipMemcpyDefault, h->stream));
+    HIP_TRY(hipMemcpyAsync(d + o_lo, lat_lo, (size_t)nq * 8, hipMemcpyDefault, h->stream));
+    HIP_TRY(hipMemcpyAsync(d + o_hi, lat_hi, (size_t)nq * 8, hipMemcpyDefault, h->stream));
+    hipLaunchKernelGGL(dmpp::k_search_obstacle_batch, dim3(nq), dim3(DMPP_WAVE), 0, h->stream, h->cfg, nq,
+                       (const GlobalPoint2D*)(d + o_paths), (const int32_t*)(d + o_poff), (const ObPoint*)(d + o_obs),
+                       (const int32_t*)(d + o_ooff), (const double*)(d + o_lo), (const double*)(d + o_hi), (Path_Obs*)(d + o_out));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d + o_out, (size_t)nq * sizeof(Path_Obs), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PP_OK;
+}
+
+int pp_geom_batch(pp_handle h, int op, int n, const GlobalPoint2D* a, const GlobalPoint2D* b, const GlobalPoint2D* c3, double* out)
+{
+    if (!h || !a || !out || op < 0 || op > 2) return fail(PP_ERR_ARG, "bad argument");
+    if ((op <= 1 && !b) || (op == 0 && !c3)) return fail(PP_ERR_ARG, "missing operand");
+    if (n <= 0) return PP_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t pb = al256((size_t)n * sizeof(GlobalPoint2D));
+    int r = need_scratch(h, 3 * pb + al256((size_t)n * 8)); if (r) return r;
+    char* d = (char*)h->d_scratch;
+    HIP_TRY(hipMemcpyAsync(d, a, (size_t)n * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    if (b) HIP_TRY(hipMemcpyAsync(d + pb, b, (size_t)n * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    if (c3) HIP_TRY(hipMemcpyAsync(d + 2 * pb, c3, (size_t)n * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    hipLaunchKernelGGL(dmpp::k_geom_batch, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->cfg, op, n, (const GlobalPoint2D*)d,
+                       (const GlobalPoint2D*)(d + pb), (const GlobalPoint2D*)(d + 2 * pb), (double*)(d + 3 * pb));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d + 3 * pb, (size_t)n * 8, hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PP_OK;
+}
+
+int pp_bezier(pp_handle h, GlobalPoint3D s, GlobalPoint3D e, GlobalPoint2D* out, int n)
+{
+    if (!h || !out || n <= 0) return fail(PP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int r = need_scratch(h, (size_t)n * sizeof(GlobalPoint2D)); if (r) return r;
+    hipLaunchKernelGGL(dmpp::k_bezier, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->cfg, s, e, (GlobalPoint2D*)h->d_scratch, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->d_scratch, (size_t)n * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PP_OK;
+}
+
+int pp_mean_points(pp_handle h, const GlobalPoint2D* in, int n_in, GlobalPoint2D* out, int n_out)
+{
+    if (!h || !out || n_out <= 0 || n_in < 0 || (n_in > 0 && !in)) return fail(PP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t ib = al256((size_t)(n_in > 0 ? n_in : 1) * sizeof(GlobalPoint2D)), cb = al256((size_t)(n_in > 0 ? n_in : 1) * 8);
+    int r = need_scratch(h, ib + cb + (size_t)n_out * sizeof(GlobalPoint2D)); if (r) return r;
+    char* d = (char*)h->d_scratch;
+    if (n_in) HIP_TRY(hipMemcpyAsync(d, in, (size_t)n_in * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    hipLaunchKernelGGL(dmpp::k_cumlen, dim3(1), dim3(DMPP_WAVE), 0, h->stream, (const GlobalPoint2D*)d, n_in, (double*)(d + ib));
+    hipLaunchKernelGGL(dmpp::k_mean_points, dim3((n_out + 255) / 256), dim3(256), 0, h->stream, h->cfg, (const GlobalPoint2D*)d,
+                       (const double*)(d + ib), n_in, (GlobalPoint2D*)(d + ib + cb), n_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d + ib + cb, (size_t)n_out * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PP_OK;
+}
+
+int pp_create_new_path(pp_handle h, const GlobalPoint2D* path, int n, double offset, GlobalPoint2D* out)
+{
+    if (!h || !path || !out || n < 0) return fail(PP_ERR_ARG, "bad argument");
+    if (n == 0) return PP_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t pb = al256((size_t)n * sizeof(GlobalPoint2D));
+    int r = need_scratch(h, 2 * pb); if (r) return r;
+    char* d = (char*)h->d_scratch;
+    HIP_TRY(hipMemcpyAsync(d, path, (size_t)n * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    hipLaunchKernelGGL(dmpp::k_create_new_path, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->cfg, (const GlobalPoint2D*)d, n, offset,
+                       (GlobalPoint2D*)(d + pb));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d + pb, (size_t)n * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+int pp_set_profile(pp_handle h, int on)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    int r = drain_events(h); if (r) return r;
+    h->profile = on != 0;
+    return PP_OK;
+}
+int pp_get_kernel_ms(pp_handle h, int k, float* ms_total, int* launches)
+{
+    if (!h || k < 0 || k >= PP_K_COUNT) return fail(PP_ERR_ARG, "bad argument");
+    int r = drain_events(h); if (r) return r;
+    if (ms_total) *ms_total = h->k_ms[k];
+    if (launches) *launches = h->k_launches[k];
+    return PP_OK;
+}
+int pp_reset_kernel_ms(pp_handle h)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    int r = drain_events(h); if (r) return r;
+    for (int k = 0; k < PP_K_COUNT; k++) { h->k_ms[k] = 0; h->k_launches[k] = 0; }
+    return PP_OK;
+}
+void* pp_device_ptr(pp_handle h, int which, size_t* bytes)
+{
+    if (!h) return nullptr;
+    const size_t ns = (size_t)h->caps.max_scenes;
+    void* p = nullptr; size_t b = 0;
+    switch (which) {
+    case PP_BUF_SCENE_IN: p = h->d_in; b = ns * sizeof(SceneIn); break;
+    case PP_BUF_LANE_POOL: p = h->d_lane; b = (size_t)h->caps.max_lane_pts_total * sizeof(GlobalPoint3D); break;
+    case PP_BUF_REF_POOL: p = h->d_ref; b = (size_t)h->caps.max_ref_pts_total * sizeof(GlobalPoint2D); break;
+    case PP_BUF_OBS_POOL: p = h->d_obs; b = (size_t)h->caps.max_obs_total * sizeof(ObPoint); break;
+    case PP_BUF_MOT_POOL: p = h->d_mot; b = (size_t)h->caps.max_obs_total * sizeof(ObMotion); break;
+    case PP_BUF_STATE: p = h->d_state; b = ns * sizeof(SceneState); break;
+    case PP_BUF_PLAN_OUT: p = h->d_plan; b = ns * sizeof(PlanOut); break;
+    case PP_BUF_GRID_OUT: p = h->d_gout; b = ns * sizeof(GridOut); break;
+    case PP_BUF_GRID: p = h->d_grid; b = ns * h->grid_cells; break;
+    case PP_BUF_PATH: p = h->d_path; b = ns * (size_t)h->max_path0 * 4; break;
+    case PP_BUF_ORDER: p = h->d_order; b = ns * (size_t)h->caps.order_cap * 4; break;
+    default: break;
+    }
+    if (bytes) *bytes = b;
+    return p;
+}
+void* pp_stream(pp_handle h) { return h ? (void*)h->stream : nullptr; }
+
+size_t pp_sizeof(int which)
+{
+    switch (which) {
+    case 0: return sizeof(PlannerConfig); case 1: return sizeof(PlannerCaps); case 2: return sizeof(SceneIn);
+    case 3: return sizeof(SceneState); case 4: return sizeof(PlanOut); case 5: return sizeof(GridOut);
+    case 6: return sizeof(ObPoint); case 7: return sizeof(ObMotion); case 8: return sizeof(Path_Obs);
+    case 9: return sizeof(LocationOut); case 10: return sizeof(DecisionOut); case 11: return sizeof(LaneView);
+    case 12: return sizeof(PlanningOut); case 13: return sizeof(PlanningStatus); case 14: return sizeof(AimPoint);
+    default: return 0;
+    }
+}
+
+}  // extern "C"

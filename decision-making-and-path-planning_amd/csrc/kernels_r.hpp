@@ -1,0 +1,601 @@
+// kernels_r.hpp — HIP kernels for the reference-real part of the tick (SURVEY.md §8 rows
+// R1-R18): one 256-thread workgroup (4 waves) per scene.
+//
+//   k_effective_obstacles : obstacle snapshot of this tick (G4 constant-velocity model)
+//   k_decision            : CDecision tick — LoadRefPath, AroundObstacle, the lateral-offset
+//                           sweep of BehaviorDecision, SpeedDecision, RefPath, and the two
+//                           junction handlers (Decision.cpp:216-486,553-673,759-1010,1781-1816)
+//   k_planning            : CPlanning tick body (Planning.cpp:114-223)
+//
+// Layout: everything a scene touches per tick is staged once into LDS (paths as 16-B
+// points read as broadcast ds_read_b128, the obstacle list as 24-B records); global reads
+// are coalesced point-per-lane copies; the 200-point steps run one point per thread; sums
+// whose rounding depends on order (arc lengths) are accumulated by one lane in index order.
+#pragma once
+#include "dev_geom.hpp"
+
+namespace dmpp {
+
+constexpr int kBlock = 256;
+constexpr int kMaxObsLds = 512;   // obstacle records staged in LDS; longer lists are read from HBM
+
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_effective_obstacles(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const SceneState* __restrict__ st,
+                      const ObPoint* __restrict__ obs, const ObMotion* __restrict__ mot, ObPoint* __restrict__ now)
+{
+    const int s = blockIdx.x;
+    if (s >= n_scenes) return;
+    const int off = in[s].obs_off, m = in[s].obs_n;
+    const double t = c.dyn_dt * (double)st[s].tick;
+    for (int j = threadIdx.x; j < m; j += kBlock) {
+        ObPoint o = obs[off + j];
+        if (c.dynamic_obstacles && mot) {
+            ObMotion v = mot[off + j];
+            o.x = o.x + v.vx * t;
+            o.y = o.y + v.vy * t;
+        }
+        now[off + j] = o;
+    }
+}
+
+// Block-wide arc-length walk shared by every branch of SearchAimPoint (Planning.cpp:410-432,
+// 448-469,478-499,507-538): accumulate |P[i+1]-P[i]| for i = i0 .. iend-1 in index order and
+// stop at the first i with sum - 4 > faraim.  Segment lengths are computed 256 at a time in
+// parallel; thread 0 adds them sequentially so the rounding equals the scalar loop.
+// base/stride: point i is (base[i*stride], base[i*stride+1]).  Returns the index or -1.
+__device__ inline int block_aim_walk(const double* base, int stride, int i0, int iend, double faraim,
+                                     double* seg, int* sh_found, double* sh_sum)
+{
+    const int tid = threadIdx.x;
+    if (i0 < 0) i0 = 0;
+    if (tid == 0) { *sh_found = -1; *sh_sum = 0; }
+    __syncthreads();
+    for (int c0 = i0; c0 < iend; c0 += kBlock) {
+        const int i = c0 + tid;
+        if (i < iend) {
+            double dx = base[(size_t)(i + 1) * stride] - base[(size_t)i * stride];
+            double dy = base[(size_t)(i + 1) * stride + 1] - base[(size_t)i * stride + 1];
+            seg[tid] = sqrt(dx * dx + dy * dy);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double sum = *sh_sum;
+            int cnt = iend - c0 < kBlock ? iend - c0 : kBlock;
+            for (int k = 0; k < cnt; k++) {
+                sum += seg[k];
+                if (sum - 4 > faraim) { *sh_found = c0 + k; break; }
+            }
+            *sh_sum = sum;
+        }
+        __syncthreads();
+        if (*sh_found >= 0) break;
+    }
+    return *sh_found;
+}
+
+// ---------------------------------------------------------------------------------------
+struct DecShared {
+    GlobalPoint2D F[DMPP_FRONT_POINTS], R[DMPP_REAR_POINTS], LF[DMPP_FRONT_POINTS], LR[DMPP_REAR_POINTS],
+                  RF[DMPP_FRONT_POINTS], RR[DMPP_REAR_POINTS];
+    GlobalPoint2D tmp[4][DMPP_FRONT_POINTS];      // one offset candidate per wave
+    GlobalPoint2D ref[DMPP_MAX_REFPATH];          // junction front path
+    double s[4][DMPP_MAX_REFPATH];                // arc-length scratch per wave
+    ObPoint obs[kMaxObsLds];
+    SoResult around[6];
+    double sweep_lng[2 * DMPP_MAX_SWEEP];
+    int n[6];
+    int n_ref, do_sweep, n_cand;
+};
+
+__device__ inline int dev_load_front(const PlannerConfig& c, const GlobalPoint3D* lane, int IdSum, int Id, GlobalPoint2D* out)
+{   // Decision.cpp:581-587
+    int lo = min(IdSum, Id + c.ID_MORE), hi = min(IdSum, Id + 120 + c.ID_MORE);
+    if (lo < 0) lo = 0;
+    int n = hi - lo; if (n < 0) n = 0;
+    for (int k = threadIdx.x; k < n; k += kBlock) { out[k].x = lane[lo + k].x; out[k].y = lane[lo + k].y; }
+    return n;
+}
+__device__ inline int dev_load_rear(const PlannerConfig& c, const GlobalPoint3D* lane, int IdSum, int Id, GlobalPoint2D* out)
+{   // Decision.cpp:590-596 (walks backwards from the ego point; index IdSum is fenced to IdSum-1)
+    int hi = min(IdSum, Id + c.ID_MORE), lo = max(0, Id + c.ID_MORE - 40);
+    int n = hi - lo; if (n < 0) n = 0;
+    if (IdSum <= 0) n = 0;
+    for (int k = threadIdx.x; k < n; k += kBlock) {
+        int i = hi - k; int q = i >= IdSum ? IdSum - 1 : i;
+        out[k].x = lane[q].x; out[k].y = lane[q].y;
+    }
+    return n;
+}
+
+__device__ inline void store_path_obs(Path_Obs* dst, const SoResult& r, const ObPoint* obs, bool searched)
+{
+    Path_Obs p;
+    p.Ob_Pose.dis_lat = searched ? r.dis_lat : 0; p.Ob_Pose.dis_lng = searched ? r.dis_lng : 0;
+    p.Obs_flag = searched ? r.flag : 0; p.Ob_Pathid = searched ? r.path_id : 0;
+    if (searched && r.flag) p.Ob_Attr = obs[r.ob_index];
+    else { p.Ob_Attr.x = 0; p.Ob_Attr.y = 0; p.Ob_Attr.type = 0; p.Ob_Attr.radius = 0; }
+    *dst = p;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const GlobalPoint3D* __restrict__ lane_pool,
+           const GlobalPoint2D* __restrict__ ref_pool, const ObPoint* __restrict__ obs_now,
+           SceneState* __restrict__ state, PlanOut* __restrict__ plan, GlobalPoint2D* __restrict__ dec_ref)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    DecShared& sh = *reinterpret_cast<DecShared*>(smem_raw);
+    const int scene = blockIdx.x;
+    if (scene >= n_scenes) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const SceneIn& si = in[scene];
+    SceneState& st = state[scene];
+    PlanOut& po = plan[scene];
+    const LocationOut& loc = si.loc;
+    const int m = si.obs_n;
+    const ObPoint* gobs = obs_now + si.obs_off;
+    const ObPoint* obs = gobs;
+    if (m <= kMaxObsLds) {
+        for (int j = tid; j < m; j += kBlock) sh.obs[j] = gobs[j];
+        obs = sh.obs;
+    }
+    const double hv = 0.5 * c.Vehicle_Width;
+    GlobalPoint2D* out_ref = dec_ref + (size_t)scene * DMPP_MAX_REFPATH;
+    const int pos = loc.pos;
+
+    if (pos == 0) {
+        // ---- LoadRefPath, Decision.cpp:553-673 ----
+        const int LaneNum_Cur = loc.lane_num, LaneSum = si.lanes.lane_sum, LaneChg = si.lanes.lanechg_attribute;
+        const int Id_Cur = loc.id[clampi(LaneNum_Cur - 1, 0, DMPP_LANESUM - 1)];
+        const double W = si.lanes.lane_width;
+        const GlobalPoint3D* cur = lane_pool + si.lanes.cur_off;
+        int nF = dev_load_front(c, cur, si.lanes.cur_n, Id_Cur, sh.F);
+        int nR = dev_load_rear(c, cur, si.lanes.cur_n, Id_Cur, sh.R);
+        int nLF = 0, nLR = 0, nRF = 0, nRR = 0;
+        int synth_left = 0, synth_right = 0;
+        if (LaneChg == 1 || LaneChg == 3) {
+            if (LaneNum_Cur > 1) {
+                int Id_L = loc.id[clampi(LaneNum_Cur - 2, 0, DMPP_LANESUM - 1)], Sum_L = si.lanes.left_n;
+                if (Id_L > 0 && Id_L < Sum_L) {
+                    const GlobalPoint3D* left = lane_pool + si.lanes.left_off;
+                    nLF = dev_load_front(c, left, Sum_L, Id_L, sh.LF);
+                    nLR = dev_load_rear(c, left, Sum_L, Id_L, sh.LR);
+                }
+            } else synth_left = 1;
+        }
+        if (LaneChg == 2) {
+            if (LaneNum_Cur < LaneSum) {
+                int Id_Rt = loc.id[clampi(LaneNum_Cur, 0, DMPP_LANESUM - 1)], Sum_Rt = si.lanes.right_n;
+                if (Id_Rt > 0 && Id_Rt < Sum_Rt) {
+                    const GlobalPoint3D* right = lane_pool + si.lanes.right_off;
+                    nRF = dev_load_front(c, right, Sum_Rt, Id_Rt, sh.RF);
+                    nRR = dev_load_rear(c, right, Sum_Rt, Id_Rt, sh.RR);
+                }
+            } else synth_right = 1;
+        }
+        __syncthreads();
+        if (synth_left) {          // Decision.cpp:629-631
+            for (int i = tid; i < nF; i += kBlock) sh.LF[i] = offset_point(c, sh.F, nF, i, -1 * W);
+            for (int i = tid; i < nR; i += kBlock) sh.LR[i] = offset_point(c, sh.R, nR, i, -1 * W);
+            nLF = nF; nLR = nR;
+        }
+        if (synth_right) {         // Decision.cpp:667-669
+            for (int i = tid; i < nF; i += kBlock) sh.RF[i] = offset_point(c, sh.F, nF, i, W);
+            for (int i = tid; i < nR; i += kBlock) sh.RR[i] = offset_point(c, sh.R, nR, i, W);
+            nRF = nF; nRR = nR;
+        }
+        __syncthreads();
+        // ---- AroundObstacle, Decision.cpp:759-881: six corridor queries over four waves ----
+        const GlobalPoint2D* P[6] = { sh.F, sh.R, sh.LF, sh.LR, sh.RF, sh.RR };
+        const int N[6] = { nF, nR, nLF, nLR, nRF, nRR };
+        const double LO[6] = { -hv, -hv, -hv, -hv, -0.5 * W, -0.5 * W };
+        const double HI[6] = { hv, hv, 0.5 * W, 0.5 * W, hv, hv };
+        for (int t = wave; t < 6; t += 4) {
+            SoResult r = wave_search_obstacle(c, P[t], N[t], sh.s[wave], obs, m, LO[t], HI[t], lane);
+            if (lane == 0) { sh.around[t] = r; sh.n[t] = N[t]; }
+        }
+        __syncthreads();
+        if (tid < 6) store_path_obs(&po.around[tid], sh.around[tid], obs, sh.n[tid] != 0);
+        // ---- BehaviorDecision, no-lane-change map: Decision.cpp:920-1010 ----
+        // (an empty front path leaves dis_lng = 0 from the memset at Decision.cpp:794)
+        const double F_lng = (nF != 0) ? sh.around[0].dis_lng : 0.0;
+        const double lim = (W - c.Vehicle_Width) / 0.6;
+        int n_cand = 0;
+        for (int i = 0; i < DMPP_MAX_SWEEP; i++) if ((double)i < lim) n_cand = i + 1;
+        const int do_sweep = (LaneChg == 0) && (F_lng < 15) && (st.obsavoid_time + 1 > 2);
+        if (do_sweep) {
+            // the candidates of both sides are independent: evaluate all, pick the first accepted
+            for (int t = wave; t < 2 * n_cand; t += 4) {
+                const int side = t / n_cand, i = t - side * n_cand;
+                const double off = (side == 0 ? -0.3 : 0.3) * (double)i;      // Decision.cpp:942,961
+                for (int k = lane; k < nF; k += DMPP_WAVE) sh.tmp[wave][k] = offset_point(c, sh.F, nF, k, off);
+                wave_sync();
+                SoResult r = wave_search_obstacle(c, sh.tmp[wave], nF, sh.s[wave], obs, m, -hv, hv, lane);
+                if (lane == 0) sh.sweep_lng[side * DMPP_MAX_SWEEP + i] = r.dis_lng;
+                wave_sync();
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            Behavior_Dec Cur;
+            Cur.behavior = st.z_behavior; Cur.light_status = st.z_light_status; Cur.target_lanenum = st.z_target_lanenum;
+            Cur.lanechg_status = st.z_segment_lanechg_status; Cur.obsavoid_status = st.z_segment_obsavoid_status;
+            Cur.behavior_to_dlg = st.z_behavior_to_dlg;
+            int sweep_side = 0, sweep_index = -1;
+            if (LaneChg == 0) {
+                if (F_lng < 15) {
+                    st.no_obsaviod_time = 0;
+                    st.obsavoid_time = st.obsavoid_time + 1;
+                    if (st.obsavoid_time > 2) {
+                        int left_flag = 0;
+                        for (int i = 0; i < n_cand; i++) if (sh.sweep_lng[i] > 25) {
+                            Cur.behavior = 4; Cur.target_lanenum = LaneNum_Cur; Cur.light_status = 1;
+                            Cur.obsavoid_status = 1; Cur.behavior_to_dlg = 11;
+                            left_flag = 1; sweep_side = -1; sweep_index = i; break;
+                        }
+                        if (!left_flag) for (int i = 0; i < n_cand; i++) if (sh.sweep_lng[DMPP_MAX_SWEEP + i] > 25) {
+                            Cur.behavior = 5; Cur.target_lanenum = LaneNum_Cur; Cur.light_status = 2;
+                            Cur.obsavoid_status = 1; Cur.behavior_to_dlg = 12;
+                            sweep_side = 1; sweep_index = i; break;
+                        }
+                    } else {
+                        Cur.behavior = 1; Cur.target_lanenum = LaneNum_Cur; Cur.light_status = 0; Cur.behavior_to_dlg = 1;
+                    }
+                } else {
+                    if (st.z_segment_obsavoid_status == 0) {
+                        Cur.behavior = 1; Cur.target_lanenum = LaneNum_Cur; Cur.light_status = 0; Cur.behavior_to_dlg = 1;
+                    } else {
+                        st.no_obsaviod_time = st.no_obsaviod_time + 1;
+                        if (st.no_obsaviod_time > 3) {
+                            Cur.behavior = 1; Cur.target_lanenum = LaneNum_Cur; Cur.light_status = 0;
+                            Cur.behavior_to_dlg = 1; Cur.obsavoid_status = 0;
+                        }
+                    }
+                    Cur.behavior_to_dlg = 1;
+                }
+            } else {
+                st.no_obsaviod_time = 0; st.obsavoid_time = 0;      // Decision.cpp:1014-1015
+            }
+            st.z_velocity_expect = (Cur.behavior == 4 || Cur.behavior == 5) ? 5 : 10;   // SpeedDecision
+            st.z_behavior = Cur.behavior; st.z_light_status = Cur.light_status; st.z_target_lanenum = Cur.target_lanenum;
+            st.z_segment_lanechg_status = Cur.lanechg_status; st.z_segment_obsavoid_status = Cur.obsavoid_status;
+            st.z_behavior_to_dlg = Cur.behavior_to_dlg; st.z_target_roadnum = loc.road_num;
+            po.sweep_side = sweep_side; po.sweep_index = sweep_index;
+            sh.n_ref = (Cur.behavior == 2) ? nLF : (Cur.behavior == 3) ? nRF : nF;      // RefPath
+            sh.do_sweep = Cur.behavior;
+        }
+        __syncthreads();
+        {
+            const int beh = sh.do_sweep;
+            const GlobalPoint2D* src = (beh == 2) ? sh.LF : (beh == 3) ? sh.RF : sh.F;
+            for (int i = tid; i < sh.n_ref; i += kBlock) out_ref[i] = src[i];
+        }
+    } else if (pos == 1 || pos == 2) {
+        // ---- PreStubDecision / StubDecision, Decision.cpp:323-486 ----
+        const GlobalPoint3D* cur = lane_pool + si.lanes.cur_off;
+        const GlobalPoint2D* inter = ref_pool + si.ref_off;
+        int n = 0;
+        if (pos == 1) {
+            int Id_Cur = max(loc.id[clampi(loc.lane_num - 1, 0, DMPP_LANESUM - 1)], 0);
+            int n1 = max(si.lanes.cur_n - Id_Cur, 0); n1 = min(n1, DMPP_MAX_REFPATH);
+            int n2 = min(max(si.ref_n, 0), DMPP_MAX_REFPATH - n1);
+            for (int k = tid; k < n1; k += kBlock) { sh.ref[k].x = cur[Id_Cur + k].x; sh.ref[k].y = cur[Id_Cur + k].y; }
+            for (int k = tid; k < n2; k += kBlock) sh.ref[n1 + k] = inter[k];
+            n = n1 + n2;
+        } else {
+            int Id_Inter = max(loc.id[clampi(loc.last_lanenum - 1, 0, DMPP_LANESUM - 1)], 0);
+            int n1 = max(si.ref_n - Id_Inter, 0); n1 = min(n1, DMPP_MAX_REFPATH);
+            int n2 = min(min(60, si.lanes.cur_n), DMPP_MAX_REFPATH - n1); n2 = max(n2, 0);
+            for (int k = tid; k < n1; k += kBlock) sh.ref[k] = inter[Id_Inter + k];
+            for (int k = tid; k < n2; k += kBlock) { sh.ref[n1 + k].x = cur[k].x; sh.ref[n1 + k].y = cur[k].y; }
+            n = n1 + n2;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            SoResult r = wave_search_obstacle(c, sh.ref, n, sh.s[0], obs, m, -hv, hv, lane);
+            if (lane == 0) sh.around[0] = r;
+        }
+        __syncthreads();
+        if (tid < 6) {
+            if (tid == 0) store_path_obs(&po.around[0], sh.around[0], obs, true);
+            else { SoResult z; z.flag = 0; z.path_id = 0; z.ob_index = -1; z.dis_lat = 0; z.dis_lng = 0; store_path_obs(&po.around[tid], z, obs, false); }
+        }
+        if (tid == 0) {
+            const double d = sh.around[0].dis_lng;
+            if (d < 13) { double v = d - 3; st.z_velocity_expect = v > 0 ? v : 0; st.z_behavior_to_dlg = 13; }
+            else { st.z_velocity_expect = 10; st.z_behavior_to_dlg = 1; }
+            st.z_light_status = (si.stub_attribute == 3) ? 1 : si.stub_attribute;
+            st.z_behavior = 1; st.z_target_roadnum = loc.road_num; st.z_target_lanenum = loc.lane_num;
+            po.sweep_side = 0; po.sweep_index = -1;
+            sh.n_ref = n;
+        }
+        for (int i = tid; i < n; i += kBlock) out_ref[i] = sh.ref[i];
+        __syncthreads();
+    } else {
+        if (tid < 6) { SoResult z; z.flag = 0; z.path_id = 0; z.ob_index = -1; z.dis_lat = 0; z.dis_lng = 0; store_path_obs(&po.around[tid], z, obs, false); }
+        if (tid == 0) { sh.n_ref = 0; po.sweep_side = 0; po.sweep_index = -1; }
+        __syncthreads();
+    }
+    if (tid == 0) {       // Decision.cpp:187-201
+        DecisionOut d;
+        d.velocity_expect = st.z_velocity_expect; d.behavior = st.z_behavior; d.target_roadnum = st.z_target_roadnum;
+        d.target_lanenum = st.z_target_lanenum; d.light = st.z_light_status; d.behavior_to_dlg = st.z_behavior_to_dlg;
+        d.refpath_n = sh.n_ref;
+        po.dec = d;
+        st.d_his_behavior = st.z_behavior; st.d_his_light_status = st.z_light_status; st.d_his_target_lanenum = st.z_target_lanenum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+struct PlanShared {
+    GlobalPoint2D last[DMPP_PATH_POINTS];
+    GlobalPoint2D road[DMPP_PATH_POINTS];
+    double dist[kBlock];           // also the 256-wide segment buffer of block_aim_walk
+    double seg[DMPP_PATH_POINTS];
+    double s[DMPP_PATH_POINTS + 8];
+    ObPoint obs[kMaxObsLds];
+    AimPoint aim_far;
+    SoResult so;
+    double sh_sum;
+    int sh_found, afresh, near_id, na;
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const GlobalPoint3D* __restrict__ lane_pool,
+           const GlobalPoint2D* __restrict__ ref_pool, const GlobalPoint2D* __restrict__ dec_ref,
+           const ObPoint* __restrict__ obs_now, SceneState* __restrict__ state, PlanOut* __restrict__ plan)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    PlanShared& sh = *reinterpret_cast<PlanShared*>(smem_raw);
+    const int scene = blockIdx.x;
+    if (scene >= n_scenes) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const SceneIn& si = in[scene];
+    SceneState& st = state[scene];
+    PlanOut& po = plan[scene];
+    const LocationOut& loc = si.loc;
+    const int pos = loc.pos;
+    const int m = si.obs_n;
+    const ObPoint* gobs = obs_now + si.obs_off;
+    const ObPoint* obs = gobs;
+    if (m <= kMaxObsLds) { for (int j = tid; j < m; j += kBlock) sh.obs[j] = gobs[j]; obs = sh.obs; }
+
+    // DecisionOut: published by k_decision into PlanOut.dec, or the caller's (decision stage off)
+    DecisionOut dec;
+    const GlobalPoint2D* refpath;
+    if (c.decision_stage) { dec = po.dec; refpath = dec_ref + (size_t)scene * DMPP_MAX_REFPATH; }
+    else {
+        dec = si.dec;
+        if (dec.refpath_n > si.ref_n) dec.refpath_n = si.ref_n;
+        if (dec.refpath_n > DMPP_MAX_REFPATH) dec.refpath_n = DMPP_MAX_REFPATH;
+        refpath = ref_pool + si.ref_off;
+    }
+    const GlobalPoint3D ego = loc.globalpoint;
+
+    // ---- Calculate_aim_dis, Planning.cpp:242-290 (FLOAT members) ----
+    float faraim = 0, nearaim = 0;
+    switch (pos) {
+    case 0:
+        faraim = (float)((loc.velocity / 3.6) * 5 + 4);
+        if (faraim > c.ROAD_FARAIM_MAX) faraim = (float)c.ROAD_FARAIM_MAX;
+        else if (faraim < c.ROAD_FARAIM_MIN) faraim = (float)c.ROAD_FARAIM_MIN;
+        nearaim = faraim; break;
+    case 1: faraim = (float)c.PRE_INTER_FARAIM; nearaim = faraim; break;
+    case 2: faraim = (float)c.INTER_FARAIM; nearaim = faraim; break;
+    default: break;
+    }
+
+    // ---- SearchAimPoint, Planning.cpp:303-583 ----
+    if (tid == 0) sh.aim_far = st.aimpoint_far;
+    AimPoint aim_near_new = st.aimpoint_near;
+    bool near_follows_far = false;
+    {
+        const int LaneNum_Cur = loc.lane_num, LaneSum = si.lanes.lane_sum;
+        const int curpoint_id = loc.id[clampi(LaneNum_Cur - 1, 0, DMPP_LANESUM - 1)];
+        const int curpoint_sum = si.lanes.cur_n;
+        int leftpoint_id = 0, leftpoint_sum = 0, rightpoint_id = 0, rightpoint_sum = 0;
+        if (LaneNum_Cur > 1) { leftpoint_id = loc.id[clampi(LaneNum_Cur - 2, 0, DMPP_LANESUM - 1)]; leftpoint_sum = si.lanes.left_n; }
+        if (LaneNum_Cur < LaneSum) { rightpoint_id = loc.id[clampi(LaneNum_Cur, 0, DMPP_LANESUM - 1)]; rightpoint_sum = si.lanes.right_n; }
+        const bool plan_div = !(fabs(faraim - nearaim) < 1);
+        const GlobalPoint3D* cur = lane_pool + si.lanes.cur_off;
+        const GlobalPoint3D* left = lane_pool + si.lanes.left_off;
+        const GlobalPoint3D* right = lane_pool + si.lanes.right_off;
+        __syncthreads();
+        if (pos == 0) {
+            if (dec.target_lanenum == loc.lane_num) {
+                if (dec.behavior == 1 && !plan_div) {
+                    int iend = curpoint_sum - 1;
+                    int f = block_aim_walk(&cur[0].x, 3, curpoint_id, iend, (double)faraim, sh.dist, &sh.sh_found, &sh.sh_sum);
+                    if (tid == 0) {
+                        if (f >= 0) { sh.aim_far.Aim_point = cur[f]; sh.aim_far.Aim_id = f; }
+                        else if (max(curpoint_id, 0) < iend) { sh.aim_far.Aim_point = cur[curpoint_sum - 1]; sh.aim_far.Aim_id = curpoint_sum - 1; }
+                    }
+                    near_follows_far = true;                               // Planning.cpp:434
+                }
+            } else if (dec.behavior == 2) {
+                if (!plan_div) {
+                    int iend = leftpoint_sum - 1;
+                    int f = block_aim_walk(&left[0].x, 3, leftpoint_id, iend, (double)faraim, sh.dist, &sh.sh_found, &sh.sh_sum);
+                    if (tid == 0) {
+                        if (f >= 0) { sh.aim_far.Aim_point = left[f]; sh.aim_far.Aim_id = f; }
+                        else if (max(leftpoint_id, 0) < iend) {             // quirk Planning.cpp:464-467
+                            int q = clampi(leftpoint_sum - 2, 0, curpoint_sum > 0 ? curpoint_sum - 1 : 0);
+                            sh.aim_far.Aim_point = cur[q]; sh.aim_far.Aim_id = leftpoint_sum - 1;
+                        }
+                    }
+                }
+            } else if (dec.behavior == 3) {
+                if (!plan_div) {
+                    int iend = min(leftpoint_sum - 1, rightpoint_sum - 1);   // quirk Planning.cpp:478 + fence
+                    int i0 = rightpoint_id;
+                    int f = (i0 >= 0) ? block_aim_walk(&right[0].x, 3, i0, iend, (double)faraim, sh.dist, &sh.sh_found, &sh.sh_sum) : -1;
+                    if (tid == 0) {
+                        if (f >= 0) { sh.aim_far.Aim_point = right[f]; sh.aim_far.Aim_id = f; }
+                        else if (i0 >= 0 && i0 < iend) { sh.aim_far.Aim_point = right[rightpoint_sum - 1]; sh.aim_far.Aim_id = rightpoint_sum - 1; }
+                    }
+                }
+            }
+        } else if (pos == 1 || pos == 2) {
+            const int n = dec.refpath_n;
+            if (n >= 3) {
+                int f = block_aim_walk(&refpath[0].x, 2, 0, n - 1, (double)faraim, sh.dist, &sh.sh_found, &sh.sh_sum);
+                if (tid == 0) {
+                    if (f >= 0) {
+                        sh.aim_far.Aim_point.x = refpath[f].x; sh.aim_far.Aim_point.y = refpath[f].y;
+                        if (f < n - 4) sh.aim_far.Aim_point.dir = GetRoadAngle(c, refpath[f], refpath[f + 2]);
+                        else sh.aim_far.Aim_point.dir = GetRoadAngle(c, refpath[f - 2 < 0 ? 0 : f - 2], refpath[f]);
+                        sh.aim_far.Aim_id = f;
+                    } else {
+                        sh.aim_far.Aim_point.x = refpath[n - 1].x; sh.aim_far.Aim_point.y = refpath[n - 1].y;
+                        sh.aim_far.Aim_point.dir = GetRoadAngle(c, refpath[n - 3], refpath[n - 1]);
+                        sh.aim_far.Aim_id = n - 1;
+                    }
+                }
+            }
+            near_follows_far = true;                                       // Planning.cpp:539,577
+        }
+    }
+    __syncthreads();
+    const AimPoint aim_far = sh.aim_far;
+    if (near_follows_far) aim_near_new = aim_far;
+
+    // ---- first tick: InitialPlanning, Planning.cpp:124-128,596-611 ----
+    const int count = st.count;
+    if (count == 0) {
+        Bezier bz = bezier_setup(c, ego, aim_far.Aim_point);
+        if (tid < DMPP_PATH_POINTS) sh.last[tid] = bezier_point(bz, tid, DMPP_PATH_POINTS);
+    } else {
+        if (tid < DMPP_PATH_POINTS) sh.last[tid] = st.last_Bpoints[tid];
+    }
+    __syncthreads();
+
+    // ---- GetVhclLocalState, Planning.cpp:623-676 ----
+    if (tid < DMPP_PATH_POINTS) {
+        double dx = ego.x - sh.last[tid].x, dy = ego.y - sh.last[tid].y;
+        sh.dist[tid] = sqrt(dx * dx + dy * dy);
+        if (tid < DMPP_PATH_POINTS - 1) {
+            double sx = sh.last[tid + 1].x - sh.last[tid].x, sy = sh.last[tid + 1].y - sh.last[tid].y;
+            sh.seg[tid] = sqrt(sx * sx + sy * sy);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double mind = 9999; int mid = clampi(st.path_near_id, 0, DMPP_PATH_POINTS - 1);
+        for (int i = 0; i < 200; i++) if (sh.dist[i] < mind) { mind = sh.dist[i]; mid = i; }   // first minimum
+        const int fid = mid + 8;
+        const int index = (mid == 199) ? mid - 1 : mid;
+        const GlobalPoint2D pt = sh.last[index], pt_next = sh.last[index + 1], vp = { ego.x, ego.y };
+        const double lat = GetLatDis(c, vp, pt, pt_next);
+        double remain = 0;
+        for (int i = fid; i < 199; i++) remain += sh.seg[i];
+        const double pt_dir = GetRoadAngle(c, pt, pt_next);
+        const double dir_err = GetAngleErr(pt_dir, ego.dir);
+        // ---- UpdatePlanJudge, Planning.cpp:797-832 ----
+        int cause = 0, afresh = 0;
+        if (st.his_behavior != dec.behavior) { cause = 1; afresh = 1; }
+        else if (fabs(lat) > 0.2) { cause = 2; afresh = 1; }
+        else if (fabs(dir_err) > 45) { cause = 3; afresh = 1; }
+        else if ((pos == 0) && remain < c.ROAD_REMAIN_DISTANCE) { cause = 4; afresh = 1; }
+        else if (pos != 0 && remain < c.INTER_REMAIN_DISTANCE) { cause = 4; afresh = 1; }
+        if (c.force_replan && !afresh) { afresh = 1; cause = 5; }
+        st.path_lat_dis = lat; st.path_dir_err = dir_err; st.remain_dis = remain;
+        st.path_near_id = mid; st.path_front_near_id = fid;
+        st.afresh_planning = afresh; st.afresh_cause = cause;
+        st.faraim_dis = faraim; st.nearaim_dis = nearaim;
+        st.aimpoint_far = aim_far; st.aimpoint_near = aim_near_new;
+        sh.afresh = afresh; sh.near_id = mid;
+        int na = aim_far.Aim_id; if (na > 200) na = 200; if (na > dec.refpath_n) na = dec.refpath_n; if (na < 0) na = 0;
+        sh.na = na;
+        // CalculateRadius, Planning.cpp:1000-1019: runs on the OLD path (called at :199, path saved at :217)
+        {
+            const int nid = clampi(mid, 0, 199), f2 = clampi(fid, 0, 199);
+            const unsigned mnum = (unsigned)round((double)((nid + f2) / 2));
+            const GlobalPoint2D a = sh.last[nid], mm = sh.last[mnum], f = sh.last[f2];
+            double dis1 = sqrt((a.x - mm.x) * (a.x - mm.x) + (a.y - mm.y) * (a.y - mm.y));
+            double dis2 = sqrt((mm.x - f.x) * (mm.x - f.x) + (mm.y - f.y) * (mm.y - f.y));
+            double dis3 = sqrt((a.x - f.x) * (a.x - f.x) + (a.y - f.y) * (a.y - f.y));
+            double dis = dis1 * dis1 + dis2 * dis2 - dis3 * dis3;
+            double cosA = dis / (2 * dis1 * dis2);
+            double sinA = sqrt(1 - cosA * cosA);
+            po.result.radius = (sinA < 0.001) ? 1000 : 0.5 * dis3 / sinA;
+        }
+    }
+    __syncthreads();
+
+    // ---- PathPlanning, Planning.cpp:845-877 (or reuse of the last path, :144-145) ----
+    const int afresh = sh.afresh;
+    if (afresh) {
+        if (pos == 0) {
+            Bezier bz = bezier_setup(c, ego, aim_far.Aim_point);
+            if (tid < DMPP_PATH_POINTS) sh.road[tid] = bezier_point(bz, tid, DMPP_PATH_POINTS);
+        } else if (pos == 1 || pos == 2) {
+            const int na = sh.na;
+            if (wave == 0) wave_cumlen(refpath, na, sh.s, lane);
+            __syncthreads();
+            if (tid < DMPP_PATH_POINTS) sh.road[tid] = mean_point(c, refpath, sh.s, na, tid, DMPP_PATH_POINTS);
+        } else {
+            if (tid < DMPP_PATH_POINTS) { sh.road[tid].x = 0; sh.road[tid].y = 0; }
+        }
+    } else {
+        if (tid < DMPP_PATH_POINTS) sh.road[tid] = sh.last[tid];
+    }
+    __syncthreads();
+
+    // ---- SearchObstacle on the remaining path, Planning.cpp:153-168 ----
+    const int near_id = clampi(sh.near_id, 0, 200);
+    if (wave == 0) {
+        SoResult r = wave_search_obstacle(c, sh.road + near_id, DMPP_PATH_POINTS - near_id, sh.s, obs, m,
+                                          (double)(float)(-1.1), (double)(float)(1.1), lane);
+        if (lane == 0) sh.so = r;
+    }
+    __syncthreads();
+
+    // ---- SpeedPlanning + publication, Planning.cpp:171-223 ----
+    if (tid == 0) {
+        const SoResult r = sh.so;
+        double brakespeed = st.brakespeed, des_acc = st.des_acc; int acc_flag = st.acc_flag;
+        const double lon = r.dis_lng;
+        if (pos == 0 || pos == 1 || pos == 2) {
+            if (r.flag) {
+                if (lon - 4 > 9) { brakespeed = 3 + (lon - 9) / (faraim - 9) * (dec.velocity_expect - 3); acc_flag = 0; des_acc = 0; }
+                else if (lon - 4 > 5) { brakespeed = 3; acc_flag = 0; des_acc = 0; }
+                else { brakespeed = 0; acc_flag = 1; des_acc = -3; }
+            } else { brakespeed = dec.velocity_expect; acc_flag = 0; des_acc = 0; }
+        }
+        st.brakespeed = brakespeed; st.des_acc = des_acc; st.acc_flag = acc_flag;
+        po.show.afresh_cause = st.afresh_cause; po.show.near_ob_dist = lon; po.show.planspeed = brakespeed;
+        po.show.planacc = des_acc; po.show.trafficlight = dec.light;
+        po.result.cnt = count % 100; po.result.APA = 0; po.result.brakedis = lon; po.result.brake_speed = 0;
+        po.result.desaccVd = acc_flag; po.result.desacc = des_acc; po.result.desspd = brakespeed; po.result.desstr = 0;
+        po.result.desstrVd = 0; po.result.light = dec.light; po.result.road_type = 0; po.result.sstop = 1; po.result._pad = 0;
+        po.ob_dis_lat = r.dis_lat; po.ob_dis_lng = lon; po.ob_flag = r.flag; po.ob_pathid = r.path_id;
+        if (r.flag) po.ob = obs[r.ob_index]; else { po.ob.x = 0; po.ob.y = 0; po.ob.type = 0; po.ob.radius = 0; }
+        po._pad[0] = 0; po._pad[1] = 0;
+        st.his_behavior = dec.behavior;
+        int cn = (count + 1) & 0xFF; if (cn % 100 == 1) cn = 1;
+        st.count = cn;
+        st.tick = st.tick + 1;
+        if (!c.decision_stage) {
+            po.dec = dec; po.sweep_side = 0; po.sweep_index = -1;
+        }
+    }
+    if (!c.decision_stage && tid < 6) {
+        SoResult z; z.flag = 0; z.path_id = 0; z.ob_index = -1; z.dis_lat = 0; z.dis_lng = 0;
+        store_path_obs(&po.around[tid], z, obs, false);
+    }
+    if (tid < DMPP_PATH_POINTS) {
+        const GlobalPoint2D p = sh.road[tid];
+        po.road_points[tid] = p;
+        st.last_Bpoints[tid] = p;                                           // Planning.cpp:217
+        if ((tid & 1) == 0) {
+            const int k = tid >> 1;
+            po.show.path_points[k] = p;                                     // Planning.cpp:180-183
+            GlobalPoint2D g;                                                // GlobalToWGS84, Planning.cpp:205-212
+            g.x = c.wgs_lat0 + p.y * c.wgs_deg_per_m_lat;
+            g.y = c.wgs_lng0 + p.x * c.wgs_deg_per_m_lng;
+            po.result.pnts[k] = g;
+        }
+    }
+}
+
+}  // namespace dmpp

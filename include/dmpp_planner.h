@@ -1,0 +1,135 @@
+/*
+ * dmpp_planner.h — C-ABI of the MI355X planning engine (libdmpp.so).
+ *
+ * The reference has no plugin/FFI interface: its boundary is the C++ class surface of
+ * CPlanning / CDecision (Planning.h:38-85, Decision.h:106-107), fed from an MFC
+ * blackboard (Planning.cpp:95-112) and drained into it (Planning.cpp:186,214).  This
+ * header is what a binding for that path binds instead: plain pointers
+ * and sizes, POD structs from dmpp_types.h, int status codes, no C++ or torch types.
+ * Every data pointer may be a host pointer or a HIP device pointer (copies use
+ * hipMemcpyDefault).  A handle owns one GPU stream and all device scratch; calls on one
+ * handle are serialised by the caller (the reference is one thread per module,
+ * Planning.cpp:24-39).  All cross-tick state is the caller-visible SceneState.
+ *
+ * Return value: 0 = ok, negative = error (pp_last_error() has the text).  Nothing here
+ * falls back to the CPU: without a usable GPU pp_create fails.
+ */
+#ifndef DMPP_PLANNER_H
+#define DMPP_PLANNER_H
+
+#include "dmpp_types.h"
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_OK            0
+#define PP_ERR_ARG      -1
+#define PP_ERR_HIP      -2
+#define PP_ERR_CAPACITY -3
+#define PP_ERR_STATE    -4
+
+/* strides of the pools filled by pp_gen_scenes */
+#define PP_GEN_LANE_PTS 320
+#define PP_GEN_REF_PTS  128
+
+typedef struct pp_planner* pp_handle;
+
+typedef struct PlannerCaps {
+    int32_t max_scenes;         /* scenes per batch */
+    int32_t max_obs_total;      /* obstacle-pool entries */
+    int32_t max_lane_pts_total; /* lane-pool points */
+    int32_t max_ref_pts_total;  /* refpath-pool points */
+    int32_t order_cap;          /* expansion-order cells kept per scene (0 = digest only) */
+    int32_t _pad;
+} PlannerCaps;
+
+/* kernels of one tick, in launch order; index into pp_get_kernel_ms */
+enum { PP_K_OBSTACLES = 0, PP_K_DECISION, PP_K_PLANNING, PP_K_RASTERISE, PP_K_SEARCH, PP_K_SCORE, PP_K_COUNT };
+/* device buffers addressable through pp_device_ptr (for RCCL scatter/gather by the caller) */
+enum { PP_BUF_SCENE_IN = 0, PP_BUF_LANE_POOL, PP_BUF_REF_POOL, PP_BUF_OBS_POOL, PP_BUF_MOT_POOL, PP_BUF_STATE,
+       PP_BUF_PLAN_OUT, PP_BUF_GRID_OUT, PP_BUF_GRID, PP_BUF_PATH, PP_BUF_ORDER, PP_BUF_COUNT };
+
+const char* pp_last_error(void);
+
+/* ---- host-side helpers (no GPU needed) ------------------------------------------------ */
+/* Values for every macro the reference leaves undefined + grid-engine defaults. */
+void pp_default_config(PlannerConfig* cfg, int grid_w, int grid_h);
+/* Zeroed state with the constructor values of Planning.cpp:10. */
+void pp_init_state(SceneState* st, int lane_num);
+/* Seeded synthetic scenes.  Pools must hold n*3*PP_GEN_LANE_PTS lane points,
+ * n*PP_GEN_REF_PTS refpath points, n*n_obs obstacles (mot_pool/state may be NULL). */
+int  pp_gen_scenes(const PlannerConfig* cfg, int first_scene, int n_scenes, int n_obs, int junction_every,
+                   SceneIn* in, GlobalPoint3D* lane_pool, GlobalPoint2D* ref_pool,
+                   ObPoint* obs_pool, ObMotion* mot_pool, SceneState* state);
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+/* Replaces CPlanning::Instance()/CDecision::Instance() + thread start (Planning.cpp:18-33). */
+int  pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_handle* out);
+int  pp_destroy(pp_handle h);
+int  pp_set_config(pp_handle h, const PlannerConfig* cfg);   /* grid size / caps may not grow */
+
+/* ---- resident-data path ------------------------------------------------------------------
+ * Replaces the blackboard reads of Planning.cpp:95-112 / Decision.cpp:155-160. */
+int  pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in,
+                   const GlobalPoint3D* lane_pool, int n_lane_pts,
+                   const GlobalPoint2D* ref_pool, int n_ref_pts,
+                   const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total);
+int  pp_set_state(pp_handle h, const SceneState* state, int n_scenes);
+/* One Decision+Planning(+grid) tick for every resident scene: the bodies of
+ * Decision.cpp:172-205 and Planning.cpp:114-223.  Asynchronous on the handle's stream. */
+int  pp_plan_tick(pp_handle h);
+int  pp_sync(pp_handle h);
+/* Replaces SetPlanningStatus/SetUdpSendCtrl (Planning.cpp:186,214) and SetDecisionOut (Decision.cpp:203). */
+int  pp_get_plan(pp_handle h, PlanOut* out, int n_scenes);
+int  pp_get_state(pp_handle h, SceneState* state, int n_scenes);
+int  pp_get_grid_out(pp_handle h, GridOut* out, int n_scenes);
+int  pp_get_grid(pp_handle h, int scene, uint8_t* grid);                 /* grid_w*grid_h bytes */
+int  pp_get_order(pp_handle h, int scene, int32_t* order, int cap);      /* needs caps.order_cap > 0 */
+int  pp_get_path(pp_handle h, int scene, int32_t* path, int cap);
+
+/* ---- one-shot batch call (the SURVEY §8b signature): upload, tick, download ---------------- */
+int  pp_plan_tick_batch(pp_handle h, int n_scenes, const SceneIn* in,
+                        const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total,
+                        const GlobalPoint3D* lane_pool, int n_lane_pts,
+                        const GlobalPoint2D* ref_pool, int n_ref_pts,
+                        SceneState* state_inout, PlanOut* out, GridOut* grid_out /* may be NULL */);
+
+/* ---- stand-alone operators on the path ------------------------------------------------------
+ * CShare::SearchObstacle (11 call sites, e.g. Planning.cpp:168, Decision.cpp:811): query q
+ * uses path points [path_off[q], path_off[q+1]) and obstacles [obs_off[q], obs_off[q+1]). */
+int  pp_search_obstacle_batch(pp_handle h, int n_queries,
+                              const GlobalPoint2D* paths, const int32_t* path_off,
+                              const ObPoint* obs, const int32_t* obs_off,
+                              const double* lat_lo, const double* lat_hi, Path_Obs* out);
+/* CPlanning::GetLatDis / GetRoadAngle / GetAngleErr (Planning.cpp:686-786), n independent items.
+ * op 0: out = GetLatDis(a[i], b[i], c[i]);  op 1: out = GetRoadAngle(a[i], b[i]);
+ * op 2: out = GetAngleErr(a[i].x, a[i].y). */
+int  pp_geom_batch(pp_handle h, int op, int n, const GlobalPoint2D* a, const GlobalPoint2D* b,
+                   const GlobalPoint2D* c, double* out);
+/* CShare::BezierPlanning / MeanPoints / CreateNewPath on one polyline each (host pointers). */
+int  pp_bezier(pp_handle h, GlobalPoint3D start, GlobalPoint3D end, GlobalPoint2D* out, int n);
+int  pp_mean_points(pp_handle h, const GlobalPoint2D* in, int n_in, GlobalPoint2D* out, int n_out);
+int  pp_create_new_path(pp_handle h, const GlobalPoint2D* path, int n, double offset, GlobalPoint2D* out);
+
+/* ---- measurement / multi-GPU plumbing --------------------------------------------------------- */
+/* When on, every kernel launch of pp_plan_tick is bracketed by HIP events on the handle's stream. */
+int   pp_set_profile(pp_handle h, int on);
+/* Sum of event-measured durations (ms) and launch count of kernel k since the last reset. */
+int   pp_get_kernel_ms(pp_handle h, int k, float* ms_total, int* launches);
+int   pp_reset_kernel_ms(pp_handle h);
+/* Raw device pointer + byte size of an internal buffer, so a caller can scatter inputs into /
+ * gather results out of it with RCCL without a host hop. */
+void* pp_device_ptr(pp_handle h, int which, size_t* bytes);
+void* pp_stream(pp_handle h);       /* hipStream_t */
+/* sizeof of an ABI struct, for bindings to check their mirror: 0 PlannerConfig, 1 PlannerCaps,
+ * 2 SceneIn, 3 SceneState, 4 PlanOut, 5 GridOut, 6 ObPoint, 7 ObMotion, 8 Path_Obs, 9 LocationOut,
+ * 10 DecisionOut, 11 LaneView, 12 PlanningOut, 13 PlanningStatus, 14 AimPoint */
+size_t pp_sizeof(int which);
+int   pp_set_n_scenes(pp_handle h, int n_scenes);  /* after filling the buffers through pp_device_ptr */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMPP_PLANNER_H */

@@ -1,0 +1,263 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded scenes.
+
+Bar (BASELINE.json north_star): integer outputs bit-exact — ids, flags, behaviour codes, replan
+cause, occupancy grid, node-expansion order, digest, counters, chosen path; floats within 1e-6
+relative.  PARITY UNPINNED versus the reference itself: it ships no tests or golden vectors and
+cannot be built here (see oracle/dmpp_oracle.h); the oracle is a line-cited restatement.
+"""
+import numpy as np
+import pytest
+
+from parity_util import compare, move_ego, bit_identical_fraction
+
+pytestmark = pytest.mark.gpu
+
+
+def _tick_both(dm, oracle, cfg, sc, n_ticks=1, order_cap=0, mutate=None, with_motion=True):
+    n = len(sc["scene_in"])
+    pl = dm.Planner(cfg, device=0, max_scenes=n, max_obs_total=max(n * sc["n_obs"], 1), order_cap=order_cap)
+    st_o = sc["state"].copy()
+    pl.set_state(sc["state"])
+    res = []
+    for t in range(n_ticks):
+        if mutate is not None:
+            mutate(sc, t)
+        pl.set_scenes(sc, with_motion=with_motion)
+        pl.tick(sync=True)
+        plan_g, st_g = pl.get_plan(), pl.get_state()
+        gout_g = pl.get_grid_out() if cfg["grid_stage"][0] else None
+        sc_o = dict(sc)
+        if not with_motion:
+            sc_o["mot_pool"] = None
+        plan_o, gout_o, grids_o = oracle.plan_tick_batch(cfg, sc_o, st_o, n_threads=8, want_grid=bool(cfg["grid_stage"][0]),
+                                                         keep_grids=bool(cfg["grid_stage"][0]) and n <= 64)
+        res.append((plan_g, st_g, gout_g, plan_o, st_o.copy(), gout_o, grids_o))
+    return pl, res
+
+
+def _assert_tick(res, tag=""):
+    plan_g, st_g, gout_g, plan_o, st_o, gout_o, _ = res
+    bad = compare(plan_g, plan_o, "plan") + compare(st_g, st_o, "state")
+    if gout_g is not None:
+        bad += compare(gout_g, gout_o, "grid")
+    assert not bad, tag + "\n" + "\n".join(bad[:20])
+
+
+# ---- stand-alone operators (rows R6, R12-R15) ---------------------------------------------------
+def test_geom_ops(dm, oracle):
+    cfg = dm.default_config(128)
+    pl = dm.Planner(cfg, max_scenes=1)
+    rng = np.random.default_rng(1)
+    n = 4096
+    a, b, c = (np.zeros(n, dm.GlobalPoint2D) for _ in range(3))
+    for arr in (a, b, c):
+        arr["x"] = rng.uniform(-50, 50, n)
+        arr["y"] = rng.uniform(-50, 50, n)
+    # degenerate cases of the EPSILON branches (Planning.cpp:690,722,724)
+    b["x"][:64] = a["x"][:64]
+    b["y"][32:64] = a["y"][32:64]
+    c["x"][64:96] = b["x"][64:96] + 1e-7
+    lat = pl.geom_batch(0, a, b, c)
+    ang = pl.geom_batch(1, a, b)
+    d = np.zeros(n, dm.GlobalPoint2D)
+    d["x"] = rng.uniform(0, 360, n)
+    d["y"] = rng.uniform(0, 360, n)
+    err = pl.geom_batch(2, d)
+    for i in range(n):
+        ai, bi, ci_ = (a["x"][i], a["y"][i]), (b["x"][i], b["y"][i]), (c["x"][i], c["y"][i])
+        assert lat[i] == oracle.GetLatDis(cfg, ai, bi, ci_)                     # +,-,*,/,sqrt only: bit-exact
+        assert abs(ang[i] - oracle.GetRoadAngle(cfg, ai, bi)) <= 1e-6 * max(1.0, abs(ang[i]))   # atan: 1e-6
+        assert err[i] == oracle.GetAngleErr(d["x"][i], d["y"][i])
+
+
+def test_helper_ops(dm, oracle):
+    cfg = dm.default_config(128)
+    pl = dm.Planner(cfg, max_scenes=1)
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        s = (rng.uniform(0, 100), rng.uniform(0, 100), rng.uniform(0, 360))
+        e = (rng.uniform(0, 100), rng.uniform(0, 100), rng.uniform(0, 360))
+        assert not compare(pl.bezier(s, e), oracle.BezierPlanning(cfg, s, e), "bezier")
+        n_in = int(rng.integers(0, 300))
+        pts = np.zeros(n_in, dm.GlobalPoint2D)
+        pts["x"] = np.cumsum(rng.uniform(0.0, 1.0, n_in))
+        pts["y"] = np.cumsum(rng.uniform(-0.5, 0.5, n_in))
+        assert not compare(pl.mean_points(pts), oracle.MeanPoints(cfg, pts), "mean")
+        if n_in:
+            off = float(rng.uniform(-4, 4))
+            g, o = pl.create_new_path(pts, off), oracle.CreateNewPath(cfg, pts, off)
+            assert g.tobytes() == o.tobytes()                                    # no transcendental: bit-exact
+    # degenerate inputs: repeated points, single point, empty
+    rep = np.zeros(5, dm.GlobalPoint2D)
+    assert not compare(pl.mean_points(rep), oracle.MeanPoints(cfg, rep), "mean-rep")
+    assert not compare(pl.mean_points(rep[:1]), oracle.MeanPoints(cfg, rep[:1]), "mean-1")
+    assert not compare(pl.mean_points(rep[:0]), oracle.MeanPoints(cfg, rep[:0]), "mean-0")
+    assert pl.create_new_path(rep, 1.0).tobytes() == oracle.CreateNewPath(cfg, rep, 1.0).tobytes()
+
+
+def test_search_obstacle_batch(dm, oracle):
+    cfg = dm.default_config(128)
+    pl = dm.Planner(cfg, max_scenes=1)
+    rng = np.random.default_rng(3)
+    paths, obs, poff, ooff, lo, hi = [], [], [0], [0], [], []
+    for q in range(200):
+        n = int(rng.choice([0, 1, 2, 3, 40, 120, 200, 513]))
+        m = int(rng.choice([0, 1, 7, 64, 65, 256]))
+        p = np.zeros(n, dm.GlobalPoint2D)
+        p["x"] = np.cumsum(rng.uniform(0.2, 0.8, n))
+        p["y"] = 3 * np.sin(p["x"] / 9.0)
+        o = np.zeros(m, dm.ObPoint)
+        o["x"] = rng.uniform(-10, (p["x"][-1] if n else 10) + 10, m)
+        o["y"] = rng.uniform(-6, 6, m)
+        o["radius"] = 1
+        if m > 2 and n > 2:      # exact ties: two obstacles at the same place, one exactly on a path point
+            o[1] = o[0]
+            o["x"][2], o["y"][2] = p["x"][n // 2], p["y"][n // 2]
+        paths.append(p); obs.append(o)
+        poff.append(poff[-1] + n); ooff.append(ooff[-1] + m)
+        w = float(rng.choice([0.9, 1.1, 1.875]))
+        lo.append(-w); hi.append(float(rng.choice([0.9, 1.875])))
+    P, Ob = np.concatenate(paths), np.concatenate(obs)
+    out = pl.search_obstacle_batch(P, np.array(poff, np.int32), Ob, np.array(ooff, np.int32), np.array(lo), np.array(hi))
+    for q in range(200):
+        r = oracle.SearchObstacle(cfg, paths[q], obs[q], lo[q], hi[q])
+        g = out[q]
+        assert int(g["Obs_flag"]) == r["flag"] and int(g["Ob_Pathid"]) == r["path_id"], q
+        assert g["Ob_Pose"]["dis_lat"] == r["dis_lat"] and g["Ob_Pose"]["dis_lng"] == r["dis_lng"], q   # bit-exact
+        assert g["Ob_Attr"].tobytes() == r["ob"].tobytes(), q
+
+
+# ---- whole tick -------------------------------------------------------------------------------------
+def test_config0_single_scene_128(dm, oracle):
+    """BASELINE configs[0]: single 128x128 grid, 8 static obstacles, one ego."""
+    cfg = dm.default_config(128)
+    sc = dm.gen_scenes(cfg, 0, 1, 8, junction_every=0)
+    pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=3, order_cap=128 * 128)
+    for t, r in enumerate(res):
+        _assert_tick(r, f"tick {t}")
+    st = sc["state"].copy()
+    for _ in range(3):
+        _, go, grid_o, order_o, path_o = oracle.plan_tick_one(cfg, sc, 0, st, order_cap=128 * 128)
+    assert (pl.get_grid(0) == grid_o).all()
+    assert (pl.get_order(0, int(go["n_expanded"])) == order_o).all()
+    assert (pl.get_path(0, int(go["path_len"])) == path_o).all()
+
+
+@pytest.mark.parametrize("n_obs", [0, 1, 64, 256])
+def test_batch_512(dm, oracle, n_obs):
+    """512x512, mixed road / pre-junction / junction scenes, every lane-change attribute."""
+    cfg = dm.default_config(512)
+    n = 96
+    sc = dm.gen_scenes(cfg, 1000, n, n_obs, junction_every=8)
+    cap = 512 * 512
+    pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=1, order_cap=cap)
+    _assert_tick(res[0], f"n_obs={n_obs}")
+    plan_g, st_g, gout_g, plan_o, st_o, gout_o, grids = res[0]
+    st = sc["state"].copy()
+    for s in range(0, n, 7):                      # full expansion order, grid and path of a sample of scenes
+        st1 = sc["state"].copy()
+        _, go, grid_o, order_o, path_o = oracle.plan_tick_one(cfg, sc, s, st1, order_cap=cap)
+        assert (pl.get_grid(s) == grid_o).all(), s
+        assert (pl.get_order(s, int(go["n_expanded"])) == order_o).all(), s
+        assert (pl.get_path(s, int(go["path_len"])) == path_o).all(), s
+    if n_obs == 64:
+        print("byte-identical fraction plan/grid:", bit_identical_fraction(plan_g, plan_o), bit_identical_fraction(gout_g, gout_o))
+
+
+def test_multi_tick_state_and_replan_causes(dm, oracle):
+    """State carried over ticks while the ego moves: exercises replan causes 1-4, the obstacle
+    counters of the sweep (Decision.cpp:915-917,936,998) and the stale-aim quirk."""
+    cfg = dm.default_config(512)
+    sc = dm.gen_scenes(cfg, 5000, 64, 64, junction_every=8)
+
+    def mutate(sc, t):
+        if t:
+            move_ego(sc, 6, dlat=0.35 if t % 3 == 2 else 0.0)
+        if t == 4:
+            sc["scene_in"]["loc"]["globalpoint"]["dir"] += 60.0          # heading error > 45 deg
+            sc["scene_in"]["loc"]["globalpoint"]["dir"] %= 360.0
+    pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=8, mutate=mutate)
+    causes = set()
+    for t, r in enumerate(res):
+        _assert_tick(r, f"tick {t}")
+        causes |= set(np.unique(r[4]["afresh_cause"]).tolist())
+    assert {0, 2, 3}.issubset(causes), causes
+    beh = np.concatenate([r[4]["z_behavior"] for r in res])
+    assert (beh == 4).any() or (beh == 5).any(), "no avoidance sweep was accepted in the sample"
+
+
+def test_decision_stage_off_and_behaviours(dm, oracle):
+    """DecisionOut supplied by the caller (lane-change behaviours 2/3 walk the left/right lane, Planning.cpp:443-501)."""
+    cfg = dm.default_config(512)
+    cfg["decision_stage"] = 0
+    sc = dm.gen_scenes(cfg, 7000, 48, 64, junction_every=6)
+    si = sc["scene_in"]
+    for s in range(48):
+        ln = int(si["loc"]["lane_num"][s])
+        if s % 3 == 1 and ln > 1:
+            si["dec"]["behavior"][s], si["dec"]["target_lanenum"][s] = 2, ln - 1
+        if s % 3 == 2 and ln < 3:
+            si["dec"]["behavior"][s], si["dec"]["target_lanenum"][s] = 3, ln + 1
+    pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=3, mutate=lambda sc, t: move_ego(sc, 4) if t else None)
+    for t, r in enumerate(res):
+        _assert_tick(r, f"tick {t}")
+
+
+def test_dynamic_obstacles_replan_every_tick(dm, oracle):
+    """BASELINE configs[3] in small: dynamic obstacles, 30-step horizon, replan forced every tick."""
+    cfg = dm.default_config(512)
+    cfg["dynamic_obstacles"] = 1
+    cfg["force_replan"] = 1
+    sc = dm.gen_scenes(cfg, 9000, 16, 256, junction_every=0)
+    pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=30)
+    for t, r in enumerate(res):
+        _assert_tick(r, f"tick {t}")
+    assert (res[-1][1]["tick"] == 30).all()
+    # the grid must actually change from tick to tick
+    assert res[0][2]["order_digest"].tolist() != res[-1][2]["order_digest"].tolist()
+
+
+def test_search_limits(dm, oracle):
+    """LIMIT, OVERFLOW, GOAL_BLOCKED, PATH_TRUNC and NO_PATH exits of the search."""
+    base = dm.default_config(512)
+    sc = dm.gen_scenes(base, 11000, 32, 64, junction_every=0)
+    for key, val in (("max_expansions", 300), ("bucket_cap", 64), ("max_path", 100)):
+        cfg = base.copy()
+        cfg[key] = val
+        pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=1)
+        plan_g, st_g, gout_g, plan_o, st_o, gout_o, _ = res[0]
+        assert (gout_g["status"] == gout_o["status"]).all(), key
+        if key != "bucket_cap":          # on OVERFLOW only the status is specified
+            _assert_tick(res[0], key)
+        want = {"max_expansions": dm.G_LIMIT, "bucket_cap": dm.G_OVERFLOW, "max_path": dm.G_PATH_TRUNC}[key]
+        assert (gout_o["status"] == want).any(), (key, np.bincount(gout_o["status"]))
+    # goal walled in: ring of obstacles around the goal -> NO_PATH; goal inside an obstacle -> GOAL_BLOCKED
+    cfg = base.copy()
+    sc2 = dm.gen_scenes(cfg, 12000, 4, 64, junction_every=0)
+    for s in range(4):
+        gx, gy = sc2["scene_in"]["goal"]["x"][s], sc2["scene_in"]["goal"]["y"][s]
+        o = sc2["obs_pool"][s * 64:(s + 1) * 64]
+        if s < 2:
+            ang = np.linspace(0, 2 * np.pi, 64, endpoint=False)
+            o["x"], o["y"], o["radius"] = gx + 6 * np.cos(ang), gy + 6 * np.sin(ang), 0.5
+        else:
+            o["x"][0], o["y"][0], o["radius"][0] = gx, gy, 1.0
+    pl, res = _tick_both(dm, oracle, cfg, sc2, n_ticks=1)
+    _assert_tick(res[0], "walled")
+    assert res[0][5]["status"].tolist()[:2] == [dm.G_NO_PATH] * 2 and res[0][5]["status"].tolist()[2:] == [dm.G_GOAL_BLOCKED] * 2
+
+
+def test_one_shot_batch_call_and_errors(dm, oracle):
+    cfg = dm.default_config(128)
+    sc = dm.gen_scenes(cfg, 300, 8, 8, junction_every=4)
+    pl = dm.Planner(cfg, max_scenes=8, max_obs_total=64)
+    st_g, st_o = sc["state"].copy(), sc["state"].copy()
+    plan_g, gout_g = pl.plan_tick_batch(sc, st_g)
+    plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st_o)
+    assert not (compare(plan_g, plan_o) + compare(st_g, st_o) + compare(gout_g, gout_o))
+    big = dm.gen_scenes(cfg, 0, 9, 8)
+    with pytest.raises(dm.PlannerError):
+        pl.set_scenes(big)                         # more scenes than caps.max_scenes
+    bad = cfg.copy(); bad["grid_w"] = 100
+    with pytest.raises(dm.PlannerError):
+        dm.Planner(bad, max_scenes=1)

@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — planning ticks/s on batched synthetic scenes (BASELINE.json metric).
+
+A "step" is one Decision+Planning+grid tick (pp_plan_tick) over one resident batch of scenes:
+BASELINE configs[1] — 1024 scenes, 512x512 occupancy grid, 64 obstacles — per GPU.  With
+--gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the scenes of all ranks are
+generated on rank 0 and SCATTERED over RCCL, every rank ticks its own shard with no data-path
+collective (scenes are independent: weak scaling, configs[2] at N = 8), and the per-scene
+digests are GATHERED back over RCCL for a cross-rank check.  Scatter/gather are outside the
+timed region (inputs resident in HBM when timing starts).
+
+Timing: W warm-up steps, barrier + device sync, K steps, barrier + device sync, MAX over ranks.
+Per-kernel durations come from HIP events recorded by the library on its own stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scenes", type=int, default=1024, help="scenes per GPU")
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--obstacles", type=int, default=64)
+    ap.add_argument("--dynamic", type=int, default=0, help="1: BASELINE configs[3] (dynamic obstacles, replan every tick)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--latency-ticks", type=int, default=200)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(cfg, n_obs):
+    """per-tick algorithmic bytes (planning tick alone, no junction refpath)."""
+    W, H = int(cfg["grid_w"][0]), int(cfg["grid_h"][0])
+    b_r = 3200 + 24 * n_obs + 128 + 3200 + 1700
+    b_g = W * H + 24 * n_obs + 3200
+    per_kernel = {                                   # per scene, per launch
+        "k_effective_obstacles": 2 * 24 * n_obs,
+        "k_decision": 480 * 24 + 24 * n_obs + 6 * 48 + 120 * 16,
+        "k_planning": b_r,
+        "k_rasterise": W * H + 24 * n_obs,           # one u8 write per cell
+        "k_search": W * H + 3200,                    # one u8 read per cell + the path out
+        "k_score": 24 * n_obs + 3200 + 3200,
+    }
+    return b_r, b_g, per_kernel
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import dmpp_amd as dm
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the planning path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    cfg = dm.default_config(args.grid)
+    if args.dynamic:
+        cfg["dynamic_obstacles"] = 1
+        cfg["force_replan"] = 1
+    n = args.scenes
+    n_obs = args.obstacles
+    pl = dm.Planner(cfg, device=local_rank, max_scenes=n, max_obs_total=max(n * n_obs, 1))
+
+    # ---- inputs: generated on rank 0, scattered over RCCL, handed to the library as device pointers ----
+    keys = ["scene_in", "lane_pool", "ref_pool", "obs_pool", "mot_pool", "state"]
+    if world == 1:
+        sc = dm.gen_scenes(cfg, 0, n, n_obs, junction_every=8)
+        pl.set_scenes(sc)
+        pl.set_state(sc["state"])
+    else:
+        shards = None
+        if rank == 0:
+            shards = [dm.gen_scenes(cfg, r * n, n, n_obs, junction_every=8) for r in range(world)]
+        proto = dm.gen_scenes(cfg, 0, 1, n_obs)      # dtypes/shapes only
+        recv = {}
+        for k in keys:
+            per_scene = len(proto[k])
+            dt = proto[k].dtype
+            nbytes = per_scene * n * dt.itemsize if k not in ("obs_pool", "mot_pool") else max(n * n_obs, 1) * dt.itemsize
+            dst = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            src = None
+            if rank == 0:
+                src = [torch.from_numpy(np.frombuffer(s[k].tobytes(), np.uint8).copy()).cuda() for s in shards]
+            dist.scatter(dst, src, src=0)
+            recv[k] = dst
+        torch.cuda.synchronize()
+        lib = pl.lib
+        dm._check(lib.pp_set_scenes(pl.h, n, recv["scene_in"].data_ptr(), recv["lane_pool"].data_ptr(), n * 3 * dm.GEN_LANE_PTS,
+                                    recv["ref_pool"].data_ptr(), n * dm.GEN_REF_PTS, recv["obs_pool"].data_ptr(),
+                                    recv["mot_pool"].data_ptr(), n * n_obs))
+        dm._check(lib.pp_set_state(pl.h, recv["state"].data_ptr(), n))
+        pl.n = n
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        pl.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pl.tick()
+    barrier()
+    pl.set_profile(True)
+    pl.reset_kernel_ms()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pl.tick()
+    barrier()
+    dt = time.perf_counter() - t0
+    kms = pl.kernel_ms()
+    pl.set_profile(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- results gathered over RCCL (digest check on rank 0) ----
+    gout = pl.get_grid_out()
+    if dist is not None:
+        mine = torch.from_numpy(gout["order_digest"].astype(np.int64)).cuda()
+        allg = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, allg, dst=0)
+        torch.cuda.synchronize()
+
+    # ---- p50 plan latency, batch = 1 (rank 0) ----
+    p50_ms = None
+    if rank == 0 and args.latency_ticks > 0:
+        pl1 = dm.Planner(cfg, device=local_rank, max_scenes=1, max_obs_total=max(n_obs, 1))
+        sc1 = dm.gen_scenes(cfg, 0, 1, n_obs, junction_every=0)
+        pl1.set_scenes(sc1)
+        pl1.set_state(sc1["state"])
+        for _ in range(10):
+            pl1.tick(sync=True)
+        lat = []
+        for _ in range(args.latency_ticks):
+            a = time.perf_counter()
+            pl1.tick(sync=True)
+            lat.append((time.perf_counter() - a) * 1e3)
+        p50_ms = float(np.percentile(lat, 50))
+        pl1.close()
+
+    # ---- CPU baseline: the oracle (a port of the path), timed on this box's host cores ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding
+        orc = oracle_binding.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+        cores = os.cpu_count() or 1
+        ns = min(n, 256)
+        scc = dm.gen_scenes(cfg, 0, ns, n_obs, junction_every=8)
+        stc = scc["state"].copy()
+        orc.plan_tick_batch(cfg, scc, stc, n_threads=cores)          # warm-up tick
+        ticks, c0 = 0, time.perf_counter()
+        while time.perf_counter() - c0 < args.cpu_seconds:
+            orc.plan_tick_batch(cfg, scc, stc, n_threads=cores)
+            ticks += 1
+        cdt = time.perf_counter() - c0
+        cpu = {"value": ns * ticks / cdt, "unit": "ticks/s", "cores": cores, "kind": "port",
+               "sample": f"{ticks} ticks x {ns} scenes of the same workload ({args.grid}x{args.grid}, {n_obs} obstacles), "
+                         f"oracle C port on {cores} pthreads, {cdt:.1f} s"}
+
+    if rank == 0:
+        b_r, b_g, per_kernel = algorithmic_bytes(cfg, n_obs)
+        dom = max(kms, key=lambda k: kms[k][0])
+        dom_ms, dom_launches = kms[dom]
+        avg_ms = dom_ms / max(dom_launches, 1)
+        achieved = per_kernel[dom] * n / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        line = {
+            "metric": "planning ticks/sec (batched scenes), %dx%d grid" % (args.grid, args.grid),
+            "value": n * world * args.steps / dt,
+            "unit": "ticks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]: %d scenes/GPU, %dx%d grid, %d %s obstacles"
+                                   % (3 if args.dynamic else (2 if world > 1 else 1), n, args.grid, args.grid, n_obs,
+                                      "dynamic" if args.dynamic else "static"),
+                       "scenes_per_gpu": n, "global_scenes": n * world, "grid": args.grid, "obstacles": n_obs,
+                       "parallelism": "scene-sharded x%d, RCCL scatter/gather outside the timed region" % world,
+                       "algorithmic_bytes_per_tick": b_r + b_g,
+                       "tick_GBps": (b_r + b_g) * n * world * args.steps / dt / 1e9},
+            "p50_plan_latency_ms_batch1": p50_ms,
+            "search_status_counts": np.bincount(gout["status"], minlength=6).tolist(),
+            "kernel_ms_avg": {k: (v[0] / max(v[1], 1)) for k, v in kms.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": per_kernel[dom] * n, "avg_launch_ms": avg_ms},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    pl.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,12 @@ PlannerCaps = _dt([("max_scenes", i4), ("max_obs_total", i4), ("max_lane_pts_tot
 _SIZEOF_ORDER = [PlannerConfig, PlannerCaps, SceneIn, SceneState, PlanOut, GridOut, ObPoint, ObMotion, Path_Obs,
                  LocationOut, DecisionOut, LaneView, PlanningOut, PlanningStatus, AimPoint]
 
+
+
+class _P3(C.Structure):          # GlobalPoint3D passed by value
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("dir", C.c_double)]
+
+
 _lib = None
 
 
@@ -124,7 +130,7 @@ def load_library(path=None):
     lib.pp_plan_tick_batch.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp]
     lib.pp_search_obstacle_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.pp_geom_batch.argtypes = [vp, ci, ci, vp, vp, vp, vp]
-    lib.pp_bezier.argtypes = [vp, C.c_double * 3, C.c_double * 3, vp, ci]
+    lib.pp_bezier.argtypes = [vp, _P3, _P3, vp, ci]
     lib.pp_mean_points.argtypes = [vp, vp, ci, vp, ci]
     lib.pp_create_new_path.argtypes = [vp, vp, ci, C.c_double, vp]
     lib.pp_set_profile.argtypes = [vp, ci]
@@ -287,7 +293,7 @@ class Planner:
 
     def bezier(self, start, end, n=PATH_POINTS):
         out = np.zeros(n, GlobalPoint2D)
-        _check(self.lib.pp_bezier(self.h, (C.c_double * 3)(*start), (C.c_double * 3)(*end), _ptr(out), n))
+        _check(self.lib.pp_bezier(self.h, _P3(*start), _P3(*end), _ptr(out), n))
         return out
 
     def mean_points(self, pts, n_out=PATH_POINTS):

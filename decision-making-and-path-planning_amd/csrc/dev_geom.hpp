@@ -20,6 +20,14 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Compiler-only ordering inside one wave (no s_waitcnt): LDS operations of a wave execute in
+// issue order, and so do its vector-memory operations on one address.
+__device__ __forceinline__ void wave_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask)

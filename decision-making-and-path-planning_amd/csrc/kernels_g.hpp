@@ -6,12 +6,13 @@
 //                 bytes and written with 16-B-per-lane coalesced stores (HBM-write bound).
 //   k_search    : bucketed A* with LIFO levels.  ONE WAVE per scene: the u8 grid is read once with
 //                 16-B-per-lane coalesced loads and packed into an LDS bitmap (blocked-or-closed,
-//                 1 bit per cell); the open set is 16 stacks (f/2 mod 16) in HBM with the stack
-//                 heights in LDS.  A step closes one node and expands it on 8 lanes (one per
+//                 1 bit per cell); the open set is 16 stacks (f/2 mod 16): the top 64 entries of each
+//                 in LDS, older ones spilled to HBM in 32-entry chunks, the heights in a lane-
+//                 spread VGPR.  A step closes one node and expands it on 8 lanes (one per
 //                 direction); successors are compacted per level with ballot + prefix popcount
 //                 in direction order, and the last one pushed onto the current level is carried
-//                 in registers as the next node (the common dive towards the goal makes no
-//                 memory round trip).  A memory pop looks at the top 8 entries at once.
+//                 in registers as the next node (the common dive towards the goal costs one LDS
+//                 round trip per step).  A stack pop looks at the top 8 entries at once.
 //   k_score     : lattice candidates (cubic Beziers to laterally shifted terminals + the grid
 //                 path) scored on collision / curvature / progress, 4 waves per scene.
 #pragma once
@@ -122,6 +123,8 @@ struct SearchScratch {          // per scene, HBM
 // blockDim = 64 (one wave).  GBM = false: the bitmap (W*H/8 bytes) is dynamic LDS — grids up to
 // 1024x1024.  GBM = true: the bitmap is a per-scene HBM/L2 scratch (2048x2048 = 512 KiB does not
 // fit the 160 KiB of LDS); same code, global loads/atomics instead of ds_ operations.
+constexpr int kWin = 64, kSpill = 32;
+
 template <bool GBM>
 __global__ void __launch_bounds__(DMPP_WAVE)
 k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict__ in, const uint8_t* __restrict__ grid,
@@ -129,13 +132,12 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
          int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ int headtail[32];
+    __shared__ uint32_t win[16][kWin];           // LDS tops of the 16 level stacks
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
     const int lane = threadIdx.x;
     const int W = c.grid_w, H = c.grid_h, N = W * H, cap = c.bucket_cap;
     uint32_t* bm = GBM ? gbitmaps + (size_t)scene * (N >> 5) : reinterpret_cast<uint32_t*>(smem_raw);   // N/32 words
-    int* tail = headtail;                                                        // stack heights of the 16 levels
     const SceneIn& si = in[scene];
     GridOut& go = gout[scene];
     const uint8_t* g = grid + (size_t)scene * N;
@@ -166,69 +168,86 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             }
         }
     }
-    if (lane < 32) headtail[lane] = 0;
-    wave_sync();
+    wave_order();
 
     const int start = cell_of(c, si.grid_origin, si.loc.globalpoint.x, si.loc.globalpoint.y);
     const int goal = cell_of(c, si.grid_origin, si.goal.x, si.goal.y);
     const int gx = goal % W, gy = goal / W;
     int status = -1, n_exp = 0, n_push = 0, n_rounds = 0, path_cost = 0;
-    uint64_t digest = 0;       // per-lane partial, summed at the end
+    uint64_t digest = 0;       // accumulated by lane 0
 
     if ((bm[goal >> 5] >> (goal & 31)) & 1u) {
         status = DMPP_G_GOAL_BLOCKED;
     } else {
-        if (lane == 0) {
-            bm[start >> 5] &= ~(1u << (start & 31));            // the vehicle is where it is
-        }
+        if (lane == 0) bm[start >> 5] &= ~(1u << (start & 31));            // the vehicle is where it is
+        wave_order();
         int fcur = hfun(start % W, start / W, gx, gy);
-        if (lane == 0) { bucket[(size_t)((fcur >> 1) & 15) * cap] = (uint32_t)start | (8u << 24); tail[(fcur >> 1) & 15] = 1; }
         n_push = 1; n_rounds = 1;
-        wave_sync();
+        // Open set: level k (= f/2 mod 16) is a stack whose top kWin entries live in LDS (win[k]) and
+        // whose older entries are spilled to HBM in chunks of kSpill.  The two heights of level k are
+        // kept in lane k of two VGPRs and read with v_readlane: no memory access to find a height.
+        int cnts = 0, gcn = 0;
         // lanes 0..7 = the eight directions of the node being expanded
         const int my_dir = lane & 7;
         const int ddx = (my_dir == 0 || my_dir == 1 || my_dir == 7) ? 1 : ((my_dir >= 3 && my_dir <= 5) ? -1 : 0);
         const int ddy = (my_dir >= 1 && my_dir <= 3) ? 1 : ((my_dir >= 5) ? -1 : 0);
         const int dcost = (my_dir & 1) ? 14 : 10;
-        bool carry = false; int carry_cell = 0, carry_dir = 0;
+        // the start node: logically pushed then popped
+        bool have_node = true; int cell = start, pd = 8;
+        // every pop either closes a cell or drops an entry: at most N closings and 8N+1 entries
+        long long guard = 10ll * N + 64;
         while (status < 0) {
+            if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
             const int b = (fcur >> 1) & 15;
-            int cell, pd;
-            if (carry) {
-                // the successor pushed last onto the current level is the next pop: it never left registers
-                cell = carry_cell; pd = carry_dir; carry = false;
-            } else {
-                const int tl = tail[b];
-                if (tl == 0) {
-                    // next non-empty level: lanes 1..15 probe, lowest wins
-                    bool ne = false;
-                    if (lane >= 1 && lane < 16) ne = tail[((fcur >> 1) + lane) & 15] != 0;
-                    const unsigned long long msk = __ballot(ne);
-                    if (msk == 0) { status = DMPP_G_NO_PATH; break; }
-                    fcur += 2 * (__ffsll((long long)msk) - 1);
+            if (!have_node) {
+                int cb = __builtin_amdgcn_readlane(cnts, b);
+                int gb = __builtin_amdgcn_readlane(gcn, b);
+                if (cb == 0 && gb == 0) {
+                    // next non-empty level: 16-bit occupancy mask rotated so that bit k = level b+k
+                    const unsigned m = (unsigned)(__ballot(lane < 16 && (cnts != 0 || gcn != 0)) & 0xFFFFull);
+                    if (m == 0) { status = DMPP_G_NO_PATH; break; }
+                    const unsigned r = ((m >> b) | (m << (16 - b))) & 0xFFFFu;
+                    fcur += 2 * (__ffs((int)r) - 1);
                     n_rounds++;
                     continue;
                 }
+                if (cb == 0) {
+                    // refill the window from the top of the spilled part
+                    const int take = min(kSpill, gb);
+                    if (lane < take) win[b][lane] = bucket[(size_t)b * cap + (gb - take) + lane];
+                    cb = take; gb -= take;
+                    if (lane == b) { cnts = cb; gcn = gb; }
+                    wave_order();
+                }
                 // look at the top 8 entries at once: the first one (from the top) that is still open is
                 // the pop; the closed ones above it are the drops a sequential pop loop would make
-                const int avail = min(tl, 8);
+                const int avail = min(cb, 8);
                 const bool have = lane < avail;
                 uint32_t e = 0;
-                if (have) e = bucket[(size_t)b * cap + (tl - 1 - lane)];
+                if (have) e = win[b][cb - 1 - lane];
                 const int ec = (int)(e & 0xFFFFFFu);
                 const bool is_open = have && !((bm[ec >> 5] >> (ec & 31)) & 1u);
-                const unsigned long long om = __ballot(is_open);
+                const unsigned om = (unsigned)__ballot(is_open);
                 if (om == 0) {
-                    if (lane == 0) tail[b] = tl - avail;
-                    wave_sync();
+                    if (lane == b) cnts = cb - avail;
                     continue;
                 }
-                const int first = __ffsll((long long)om) - 1;
-                e = (uint32_t)__shfl((int)e, first, 64);
+                const int first = __ffs((int)om) - 1;
+                e = (uint32_t)__builtin_amdgcn_readlane((int)e, first);
                 cell = (int)(e & 0xFFFFFFu); pd = (int)(e >> 24);
-                if (lane == 0) tail[b] = tl - (first + 1);
-                wave_sync();
+#ifdef DMPP_DEBUG_SEARCH
+                if (e == 0) {
+                    if (lane == 0) { path[0] = n_exp; path[1] = b; path[2] = cb; path[3] = gb; path[4] = first; path[5] = fcur; path[6] = (int)om; path[7] = avail; }
+                    if (lane < 16) { path[8 + lane] = cnts; path[24 + lane] = gcn; }
+                    path[40 + lane] = (int)win[b][lane];
+                    path[104 + lane] = (int)win[lane & 15][lane >> 4];
+                    wave_order(); win[b][63 - lane] = 0x1230000u | (unsigned)lane; wave_order(); path[168 + lane] = (int)win[b][lane];
+                    status = DMPP_G_INTERNAL; break;
+                }
+#endif
+                if (lane == b) cnts = cb - (first + 1);
             }
+            have_node = false;
             // ---- close: bitmap, parent, order, digest ----
             if (lane == 0) {
                 bm[cell >> 5] |= 1u << (cell & 31);
@@ -237,7 +256,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 digest += mix64(((uint64_t)(uint32_t)n_exp << 32) | (uint32_t)cell);
             }
             n_exp++;
-            wave_sync();
+            wave_order();
             if (cell == goal) { status = DMPP_G_FOUND; path_cost = fcur; break; }
             if (n_exp >= c.max_expansions) { status = DMPP_G_LIMIT; break; }
             // ---- expand on lanes 0..7 ----
@@ -245,42 +264,50 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             const int nx = x + ddx, ny = y + ddy;
             const bool inb = lane < 8 && nx >= 0 && ny >= 0 && nx < W && ny < H;
             const int ncell = inb ? ny * W + nx : 0;
-            bool push = inb && !((bm[ncell >> 5] >> (ncell & 31)) & 1u);
-            int kb = -1;
-            if (push) {
-                const int gcur = fcur - hfun(x, y, gx, gy);
-                const int fn = gcur + dcost + hfun(nx, ny, gx, gy);
-                kb = (fn >> 1) & 15;
+            const int gcur = fcur - hfun(x, y, gx, gy);
+            const int kb = ((gcur + dcost + hfun(nx, ny, gx, gy)) >> 1) & 15;     // level of the successor
+            const bool push = inb && !((bm[ncell >> 5] >> (ncell & 31)) & 1u);
+            const unsigned pm = (unsigned)__ballot(push);
+            n_push += __popc(pm);
+            // the last push onto the current level is the next pop: it stays in registers
+            const unsigned cm = (unsigned)__ballot(push && kb == b);
+            int top = -1;
+            if (cm) {
+                top = 31 - __clz((int)cm);
+                cell = __builtin_amdgcn_readlane(ncell, top); pd = top; have_node = true;
             }
-            unsigned long long rem = __ballot(push);
-            n_push += __popcll(rem);
-            // ---- push per level in direction order; the last push onto the current level is carried ----
+            // ---- push per level, in direction order ----
             bool overflow = false;
+            unsigned rem = pm;
             while (rem) {
-                const int src = __ffsll((long long)rem) - 1;
-                const int kk = __shfl(kb, src, 64);
-                const unsigned long long mk = __ballot(push && kb == kk);
-                const int base = tail[kk];
-                const int cnt = __popcll(mk);
-                if (base + cnt > cap) { overflow = true; break; }
-                int stored = cnt;
-                unsigned long long smk = mk;
-                if (kk == b) {
-                    const int top = 63 - __clzll((long long)mk);          // highest direction on this level
-                    carry = true; carry_cell = __shfl(ncell, top, 64); carry_dir = top;
-                    smk = mk & ~(1ull << top); stored = cnt - 1;
-                }
-                if (push && kb == kk && ((smk >> lane) & 1ull)) {
-                    const int r = __popcll(smk & ((1ull << lane) - 1ull));
-                    bucket[(size_t)kk * cap + base + r] = (uint32_t)ncell | ((uint32_t)my_dir << 24);
-                }
-                if (stored) {
-                    wave_sync();
-                    if (lane == 0) tail[kk] = base + stored;
-                    wave_sync();
-                }
+                const int q = __ffs((int)rem) - 1;
+                const int kk = __builtin_amdgcn_readlane(kb, q);
+                const unsigned mk = (unsigned)__ballot(push && kb == kk);
                 rem &= ~mk;
+                const int cnt = __popc(mk);
+                int base = __builtin_amdgcn_readlane(cnts, kk);
+                int gbase = __builtin_amdgcn_readlane(gcn, kk);
+                if (base + gbase + cnt > cap) { overflow = true; break; }
+                const unsigned smk = (kk == b && top >= 0) ? (mk & ~(1u << top)) : mk;   // the carried one is not stored
+                const int stored = __popc(smk);
+                if (stored == 0) continue;
+                if (base + stored > kWin) {
+                    // spill the bottom kSpill entries of the window to HBM, slide the rest down
+                    uint32_t v = 0;
+                    if (lane < base) v = win[kk][lane];
+                    wave_order();
+                    if (lane < kSpill) bucket[(size_t)kk * cap + gbase + lane] = v;
+                    else if (lane < base) win[kk][lane - kSpill] = v;
+                    base -= kSpill; gbase += kSpill;
+                    wave_order();
+                }
+                if (lane < 8 && ((smk >> lane) & 1u)) {              // lanes 0..7 only: the masks are 32-bit
+                    const int r = __popc(smk & ((1u << lane) - 1u));
+                    win[kk][base + r] = (uint32_t)ncell | ((uint32_t)my_dir << 24);
+                }
+                if (lane == kk) { cnts = base + stored; gcn = gbase; }
             }
+            wave_order();
             if (overflow) { status = DMPP_G_OVERFLOW; break; }
         }
     }
@@ -302,8 +329,8 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         if (lane == 0) {
             int cur = goal;
             rev[0] = cur;
-            while (cur != start) {
-                const int pd = parent[cur];
+            while (cur != start && L <= N) {
+                const int pd = parent[cur] & 7;
                 const int dx = (pd == 0 || pd == 1 || pd == 7) ? 1 : ((pd >= 3 && pd <= 5) ? -1 : 0);
                 const int dy = (pd >= 1 && pd <= 3) ? 1 : ((pd >= 5) ? -1 : 0);
                 cur -= dy * W + dx;
@@ -312,8 +339,9 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             }
         }
         L = __shfl(L, 0, 64);
+        if (L > N) { status = DMPP_G_INTERNAL; L = 1; }
         int keep = L;
-        if (L > c.max_path) { keep = c.max_path; status = DMPP_G_PATH_TRUNC; }
+        if (status == DMPP_G_FOUND && L > c.max_path) { keep = c.max_path; status = DMPP_G_PATH_TRUNC; }
         path_len = keep;
         wave_sync();
         for (int k = lane; k < keep; k += DMPP_WAVE) path[keep - 1 - k] = rev[k];

@@ -156,6 +156,7 @@ typedef struct SceneIn {
 #define DMPP_G_OVERFLOW   3   /* an open-set bucket exceeded bucket_cap */
 #define DMPP_G_GOAL_BLOCKED 4 /* goal cell occupied: no search run */
 #define DMPP_G_PATH_TRUNC 5   /* path longer than max_path cells */
+#define DMPP_G_INTERNAL   6   /* a loop bound of the device search was hit: never expected, reported instead of hanging */
 
 #define DMPP_MAX_LATTICE 17   /* n_lattice Bezier candidates + 1 grid-path candidate */
 

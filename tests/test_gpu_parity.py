@@ -224,6 +224,8 @@ def test_search_limits(dm, oracle):
     for key, val in (("max_expansions", 300), ("bucket_cap", 64), ("max_path", 100)):
         cfg = base.copy()
         cfg[key] = val
+        if key == "bucket_cap":
+            cfg["max_path"] = 1024                  # the ABI requires 16*bucket_cap >= max_path
         pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=1)
         plan_g, st_g, gout_g, plan_o, st_o, gout_o, _ = res[0]
         assert (gout_g["status"] == gout_o["status"]).all(), key

@@ -4,15 +4,14 @@
 //   k_rasterise : obstacle list -> u8 occupancy grid in HBM.  One workgroup per (scene, band of
 //                 rows): footprints are OR-ed into an LDS bit band, then the band is expanded to
 //                 bytes and written with 16-B-per-lane coalesced stores (HBM-write bound).
-//   k_search    : bucketed A* with LIFO levels.  ONE WAVE per scene: the u8 grid is read once with
-//                 16-B-per-lane coalesced loads and packed into an LDS bitmap (blocked-or-closed,
-//                 1 bit per cell); the open set is 16 stacks (f/2 mod 16): the top 64 entries of each
-//                 in LDS, older ones spilled to HBM in 32-entry chunks, the heights in a lane-
-//                 spread VGPR.  A step closes one node and expands it on 8 lanes (one per
-//                 direction); successors are compacted per level with ballot + prefix popcount
-//                 in direction order, and the last one pushed onto the current level is carried
-//                 in registers as the next node (the common dive towards the goal costs one LDS
-//                 round trip per step).  A stack pop looks at the top 8 entries at once.
+//   k_search    : bucketed A* with LIFO levels, batches of 8.  ONE WAVE per scene: the u8 grid is read
+//                 once with 16-B-per-lane coalesced loads and packed into an LDS bitmap (blocked-
+//                 or-closed, 1 bit per cell); the open set is 16 stacks (f/2 mod 16): the top <= 96
+//                 entries of each in LDS, older ones spilled to HBM in 32-entry chunks, the heights
+//                 in a lane-spread VGPR.  A step takes the top 8 entries of the current level,
+//                 closes the open distinct ones and expands them on 8 x 8 lanes (node x direction);
+//                 successors are compacted per level with ballot + mbcnt prefix ranks, in batch
+//                 order then direction order.  No memory wait except LDS in the common step.
 //   k_score     : lattice candidates (cubic Beziers to laterally shifted terminals + the grid
 //                 path) scored on collision / curvature / progress, 4 waves per scene.
 #pragma once
@@ -123,7 +122,7 @@ struct SearchScratch {          // per scene, HBM
 // blockDim = 64 (one wave).  GBM = false: the bitmap (W*H/8 bytes) is dynamic LDS — grids up to
 // 1024x1024.  GBM = true: the bitmap is a per-scene HBM/L2 scratch (2048x2048 = 512 KiB does not
 // fit the 160 KiB of LDS); same code, global loads/atomics instead of ds_ operations.
-constexpr int kWin = 64, kSpill = 32;
+constexpr int kWin = 96, kSpill = 32;   // LDS window per level: 8 kept + up to 64 pushed per step + one chunk
 
 template <bool GBM>
 __global__ void __launch_bounds__(DMPP_WAVE)
@@ -174,138 +173,137 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     const int goal = cell_of(c, si.grid_origin, si.goal.x, si.goal.y);
     const int gx = goal % W, gy = goal / W;
     int status = -1, n_exp = 0, n_push = 0, n_rounds = 0, path_cost = 0;
-    uint64_t digest = 0;       // accumulated by lane 0
+    uint64_t digest = 0;       // per-lane partial, summed at the end
 
     if ((bm[goal >> 5] >> (goal & 31)) & 1u) {
         status = DMPP_G_GOAL_BLOCKED;
     } else {
         if (lane == 0) bm[start >> 5] &= ~(1u << (start & 31));            // the vehicle is where it is
-        wave_order();
         int fcur = hfun(start % W, start / W, gx, gy);
-        n_push = 1; n_rounds = 1;
-        // Open set: level k (= f/2 mod 16) is a stack whose top kWin entries live in LDS (win[k]) and
-        // whose older entries are spilled to HBM in chunks of kSpill.  The two heights of level k are
-        // kept in lane k of two VGPRs and read with v_readlane: no memory access to find a height.
+        // Open set: level k (= f/2 mod 16) is a stack whose top (<= kWin entries) lives in LDS (win[k])
+        // and whose older entries are spilled to HBM.  The two heights of level k are kept in lane k
+        // of two VGPRs and read with v_readlane.  An entry is x | y << 12 | arriving direction << 24.
         int cnts = 0, gcn = 0;
-        // lanes 0..7 = the eight directions of the node being expanded
-        const int my_dir = lane & 7;
+        {
+            const int b0 = (fcur >> 1) & 15;
+            if (lane == 0) win[b0][0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
+            if (lane == b0) cnts = 1;
+        }
+        n_push = 1; n_rounds = 1;
+        wave_order();
+        // lane = node * 8 + direction: 8 batch nodes x 8 directions
+        const int node = lane >> 3, my_dir = lane & 7;
         const int ddx = (my_dir == 0 || my_dir == 1 || my_dir == 7) ? 1 : ((my_dir >= 3 && my_dir <= 5) ? -1 : 0);
         const int ddy = (my_dir >= 1 && my_dir <= 3) ? 1 : ((my_dir >= 5) ? -1 : 0);
         const int dcost = (my_dir & 1) ? 14 : 10;
-        // the start node: logically pushed then popped
-        bool have_node = true; int cell = start, pd = 8;
-        // every pop either closes a cell or drops an entry: at most N closings and 8N+1 entries
+        const unsigned long long below_node = (1ull << (node * 8)) - 1ull;      // lanes of earlier nodes
+        // every step consumes at least one entry; there are at most 8N+1 entries
         long long guard = 10ll * N + 64;
         while (status < 0) {
             if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
             const int b = (fcur >> 1) & 15;
-            if (!have_node) {
-                int cb = __builtin_amdgcn_readlane(cnts, b);
-                int gb = __builtin_amdgcn_readlane(gcn, b);
-                if (cb == 0 && gb == 0) {
-                    // next non-empty level: 16-bit occupancy mask rotated so that bit k = level b+k
-                    const unsigned m = (unsigned)(__ballot(lane < 16 && (cnts != 0 || gcn != 0)) & 0xFFFFull);
-                    if (m == 0) { status = DMPP_G_NO_PATH; break; }
-                    const unsigned r = ((m >> b) | (m << (16 - b))) & 0xFFFFu;
-                    fcur += 2 * (__ffs((int)r) - 1);
-                    n_rounds++;
-                    continue;
-                }
-                if (cb == 0) {
-                    // refill the window from the top of the spilled part
-                    const int take = min(kSpill, gb);
-                    if (lane < take) win[b][lane] = bucket[(size_t)b * cap + (gb - take) + lane];
-                    cb = take; gb -= take;
-                    if (lane == b) { cnts = cb; gcn = gb; }
-                    wave_order();
-                }
-                // look at the top 8 entries at once: the first one (from the top) that is still open is
-                // the pop; the closed ones above it are the drops a sequential pop loop would make
-                const int avail = min(cb, 8);
-                const bool have = lane < avail;
-                uint32_t e = 0;
-                if (have) e = win[b][cb - 1 - lane];
-                const int ec = (int)(e & 0xFFFFFFu);
-                const bool is_open = have && !((bm[ec >> 5] >> (ec & 31)) & 1u);
-                const unsigned om = (unsigned)__ballot(is_open);
-                if (om == 0) {
-                    if (lane == b) cnts = cb - avail;
-                    continue;
-                }
-                const int first = __ffs((int)om) - 1;
-                e = (uint32_t)__builtin_amdgcn_readlane((int)e, first);
-                cell = (int)(e & 0xFFFFFFu); pd = (int)(e >> 24);
-#ifdef DMPP_DEBUG_SEARCH
-                if (e == 0) {
-                    if (lane == 0) { path[0] = n_exp; path[1] = b; path[2] = cb; path[3] = gb; path[4] = first; path[5] = fcur; path[6] = (int)om; path[7] = avail; }
-                    if (lane < 16) { path[8 + lane] = cnts; path[24 + lane] = gcn; }
-                    path[40 + lane] = (int)win[b][lane];
-                    path[104 + lane] = (int)win[lane & 15][lane >> 4];
-                    wave_order(); win[b][63 - lane] = 0x1230000u | (unsigned)lane; wave_order(); path[168 + lane] = (int)win[b][lane];
-                    status = DMPP_G_INTERNAL; break;
-                }
-#endif
-                if (lane == b) cnts = cb - (first + 1);
+            int cb = __builtin_amdgcn_readlane(cnts, b);
+            int gb = __builtin_amdgcn_readlane(gcn, b);
+            if (cb == 0 && gb == 0) {
+                // next non-empty level: 16-bit occupancy mask rotated so that bit k = level b+k
+                const unsigned m = (unsigned)(__ballot(lane < 16 && (cnts != 0 || gcn != 0)) & 0xFFFFull);
+                if (m == 0) { status = DMPP_G_NO_PATH; break; }
+                const unsigned r = ((m >> b) | (m << (16 - b))) & 0xFFFFu;
+                fcur += 2 * (__ffs((int)r) - 1);
+                n_rounds++;
+                continue;
             }
-            have_node = false;
-            // ---- close: bitmap, parent, order, digest ----
-            if (lane == 0) {
-                bm[cell >> 5] |= 1u << (cell & 31);
+            if (cb < 8 && gb > 0) {
+                // slide the (< 8) window entries up and pull a chunk of the spilled part in underneath
+                const int take = min(kSpill, gb);
+                uint32_t v = 0;
+                if (lane < cb) v = win[b][lane];
+                wave_order();
+                if (lane < cb) win[b][lane + take] = v;
+                if (lane < take) win[b][lane] = bucket[(size_t)b * cap + (gb - take) + lane];
+                cb += take; gb -= take;
+                if (lane == b) gcn = gb;
+                wave_order();
+            }
+            // ---- pop phase: the top min(8, height) entries, node q = q-th from the top ----
+            const int avail = min(cb, 8);
+            const bool have = node < avail;
+            uint32_t e = 0;
+            if (have) e = win[b][cb - 1 - node];
+            const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu), pd = (int)(e >> 24);
+            const int cell = y * W + x;
+            bool valid = have && !((bm[cell >> 5] >> (cell & 31)) & 1u);
+            {   // a cell that appears twice among the 8: the one nearer the top wins
+                const unsigned long long om = __ballot(valid);
+                bool dup = false;
+#pragma unroll
+                for (int q = 0; q < 7; q++) {
+                    const int cq = __builtin_amdgcn_readlane(cell, q * 8);
+                    if (q < node && ((om >> (q * 8)) & 1ull) && cq == cell) dup = true;
+                }
+                if (dup) valid = false;
+            }
+            // the goal, or the node that reaches the expansion limit, ends the search at once:
+            // entries below it are not looked at
+            unsigned long long vm = __ballot(valid && my_dir == 0);                 // bit 8q = node q joins the batch
+            {
+                const int nvb = __popcll(vm & below_node);
+                const unsigned long long stop = __ballot(valid && my_dir == 0 && (cell == goal || n_exp + nvb + 1 >= c.max_expansions));
+                if (stop) {
+                    const int last = (__ffsll((long long)stop) - 1) >> 3;
+                    if (node > last) valid = false;
+                    vm = __ballot(valid && my_dir == 0);
+                }
+            }
+            // ---- close: bitmap, parent, order, digest (one lane per batch node) ----
+            if (valid && my_dir == 0) {
+                const int seq = n_exp + __popcll(vm & below_node);
+                atomicOr(&bm[cell >> 5], 1u << (cell & 31));
                 parent[cell] = (uint8_t)pd;
-                if (order && n_exp < order_cap) order[n_exp] = cell;
-                digest += mix64(((uint64_t)(uint32_t)n_exp << 32) | (uint32_t)cell);
+                if (order && seq < order_cap) order[seq] = cell;
+                digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell);
             }
-            n_exp++;
+            n_exp += __popcll(vm);
+            if (lane == b) cnts = cb - avail;
             wave_order();
-            if (cell == goal) { status = DMPP_G_FOUND; path_cost = fcur; break; }
+            if (__ballot(valid && cell == goal)) { status = DMPP_G_FOUND; path_cost = fcur; break; }
             if (n_exp >= c.max_expansions) { status = DMPP_G_LIMIT; break; }
-            // ---- expand on lanes 0..7 ----
-            const int x = cell % W, y = cell / W;
+            // ---- expand phase: every lane tests one (node, direction) ----
             const int nx = x + ddx, ny = y + ddy;
-            const bool inb = lane < 8 && nx >= 0 && ny >= 0 && nx < W && ny < H;
+            const bool inb = valid && nx >= 0 && ny >= 0 && nx < W && ny < H;
             const int ncell = inb ? ny * W + nx : 0;
-            const int gcur = fcur - hfun(x, y, gx, gy);
-            const int kb = ((gcur + dcost + hfun(nx, ny, gx, gy)) >> 1) & 15;     // level of the successor
             const bool push = inb && !((bm[ncell >> 5] >> (ncell & 31)) & 1u);
-            const unsigned pm = (unsigned)__ballot(push);
-            n_push += __popc(pm);
-            // the last push onto the current level is the next pop: it stays in registers
-            const unsigned cm = (unsigned)__ballot(push && kb == b);
-            int top = -1;
-            if (cm) {
-                top = 31 - __clz((int)cm);
-                cell = __builtin_amdgcn_readlane(ncell, top); pd = top; have_node = true;
-            }
-            // ---- push per level, in direction order ----
+            const int kb = (b + ((dcost + hfun(nx, ny, gx, gy) - hfun(x, y, gx, gy)) >> 1)) & 15;   // level of the successor
+            unsigned long long rem = __ballot(push);
+            n_push += __popcll(rem);
+            // ---- push per level in lane order (= batch order, then direction order) ----
             bool overflow = false;
-            unsigned rem = pm;
             while (rem) {
-                const int q = __ffs((int)rem) - 1;
+                const int q = __ffsll((long long)rem) - 1;
                 const int kk = __builtin_amdgcn_readlane(kb, q);
-                const unsigned mk = (unsigned)__ballot(push && kb == kk);
+                const bool mine = push && kb == kk;
+                const unsigned long long mk = __ballot(mine);
                 rem &= ~mk;
-                const int cnt = __popc(mk);
+                const int cnt = __popcll(mk);
                 int base = __builtin_amdgcn_readlane(cnts, kk);
                 int gbase = __builtin_amdgcn_readlane(gcn, kk);
                 if (base + gbase + cnt > cap) { overflow = true; break; }
-                const unsigned smk = (kk == b && top >= 0) ? (mk & ~(1u << top)) : mk;   // the carried one is not stored
-                const int stored = __popc(smk);
-                if (stored == 0) continue;
-                if (base + stored > kWin) {
-                    // spill the bottom kSpill entries of the window to HBM, slide the rest down
+                if (base + cnt > kWin) {
+                    // spill the bottom 32 or 64 entries of the window to HBM, slide the rest down
+                    const int sp = ((base + cnt - kWin + kSpill - 1) / kSpill) * kSpill;
+                    if (lane < sp) bucket[(size_t)kk * cap + gbase + lane] = win[kk][lane];
                     uint32_t v = 0;
-                    if (lane < base) v = win[kk][lane];
+                    if (lane < base - sp) v = win[kk][sp + lane];
                     wave_order();
-                    if (lane < kSpill) bucket[(size_t)kk * cap + gbase + lane] = v;
-                    else if (lane < base) win[kk][lane - kSpill] = v;
-                    base -= kSpill; gbase += kSpill;
+                    if (lane < base - sp) win[kk][lane] = v;
+                    base -= sp; gbase += sp;
                     wave_order();
                 }
-                if (lane < 8 && ((smk >> lane) & 1u)) {              // lanes 0..7 only: the masks are 32-bit
-                    const int r = __popc(smk & ((1u << lane) - 1u));
-                    win[kk][base + r] = (uint32_t)ncell | ((uint32_t)my_dir << 24);
+                if (mine) {
+                    const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                    win[kk][base + r] = (uint32_t)nx | ((uint32_t)ny << 12) | ((uint32_t)my_dir << 24);
                 }
-                if (lane == kk) { cnts = base + stored; gcn = gbase; }
+                if (lane == kk) { cnts = base + cnt; gcn = gbase; }
             }
             wave_order();
             if (overflow) { status = DMPP_G_OVERFLOW; break; }

@@ -77,21 +77,25 @@ void orc_rasterise(const PlannerConfig* c, GlobalPoint2D origin, const ObPoint* 
 }
 
 /* ------------------------------------------------------------------------------ */
-/* G2: bucketed A* with LIFO levels (Dial's buckets over f = g + h, depth-first tie-breaking).
+/* G2: bucketed A* with LIFO levels, expanded in batches of 8 (Dial's buckets over f = g + h,
+ * depth-first tie-breaking, batch-synchronous so that 8 nodes x 8 directions fill a 64-lane wave).
  *   moves   : 8-connected, direction d = 0..7 = E,NE,N,NW,W,SW,S,SE, cost 10 (even d) / 14 (odd d);
  *             a move is legal iff the target cell is inside the grid, not occupied, not closed.
  *   h       : octile, 10*max(|dx|,|dy|) + 4*min(|dx|,|dy|)  (consistent, so f never decreases
  *             and a successor's f is within [f, f+28]; all f are even -> ring of 16 levels).
  *   open set: one STACK per f level.  Entries are (cell, arriving direction).  A cell may be
- *             stacked several times; an entry whose cell is already closed is dropped when popped.
- *   order   : pop the top of the stack of the lowest non-empty f; successors are pushed in
- *             direction order 0..7 (so the last legal direction with f' = f is expanded next:
- *             the search dives towards the goal and only falls back to older entries at dead
- *             ends).  The k-th cell closed is expansion k.
- *   stop    : goal closed (FOUND) | open set empty (NO_PATH) | n_expanded == max_expansions (LIMIT)
- *             | a stack would hold more than bucket_cap entries (OVERFLOW).
+ *             stacked several times.
+ *   step    : take the top min(8, height) entries of the stack of the lowest non-empty f, from the
+ *             top down; each one whose cell is not closed is closed (expansion k = the k-th cell
+ *             closed) and joins the batch; the others are dropped.  Then every batch node, in the
+ *             order it was closed, pushes its legal successors in direction order 0..7 (legality
+ *             is tested after the whole batch has been closed).
+ *   stop    : goal closed (FOUND, at once: later entries of the step are not looked at) | open set
+ *             empty (NO_PATH) | n_expanded == max_expansions (LIMIT, at once) | a stack would hold
+ *             more than bucket_cap entries (OVERFLOW).
  *   path    : follow the arriving directions back from the goal.
  */
+#define ORC_BATCH 8
 static const int DX[8] = { 1, 1, 0, -1, -1, -1, 0, 1 };
 static const int DY[8] = { 0, 1, 1, 1, 0, -1, -1, -1 };
 
@@ -143,27 +147,39 @@ void orc_grid_search(const PlannerConfig* c, const uint8_t* grid, int start_cell
             fcur += 2 * k; out->n_rounds++;
             continue;
         }
-        uint32_t e = bucket[(size_t)b * cap + --tail[b]];
-        int cell = (int)(e & 0xFFFFFFu), pd = (int)(e >> 24);
-        if (closed[cell]) continue;
-        closed[cell] = 1; parent[cell] = (uint8_t)pd;
-        int seq = out->n_expanded++;
-        if (order && seq < order_cap) order[seq] = cell;
-        out->order_digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell);
-        if (cell == goal_cell) { status = DMPP_G_FOUND; out->path_cost = fcur; break; }
-        if (out->n_expanded >= c->max_expansions) { status = DMPP_G_LIMIT; break; }
-        int x = cell % W, y = cell / W;
-        int g = fcur - hfun(x, y, gx, gy);
-        for (int d = 0; d < 8 && status < 0; d++) {
-            int nx = x + DX[d], ny = y + DY[d];
-            if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
-            int n = ny * W + nx;
-            if (closed[n]) continue;
-            int fn = g + ((d & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
-            int bb = (fn / 2) % 16;
-            if (tail[bb] >= cap) { status = DMPP_G_OVERFLOW; break; }
-            bucket[(size_t)bb * cap + tail[bb]++] = (uint32_t)n | ((uint32_t)d << 24);
-            out->n_pushed++;
+        /* pop phase */
+        int take = tail[b] < ORC_BATCH ? tail[b] : ORC_BATCH;
+        int batch[ORC_BATCH], nb = 0;
+        for (int q = 0; q < take && status < 0; q++) {
+            uint32_t e = bucket[(size_t)b * cap + (tail[b] - 1 - q)];
+            int cell = (int)(e & 0xFFFFFFu), pd = (int)(e >> 24);
+            if (closed[cell]) continue;
+            closed[cell] = 1; parent[cell] = (uint8_t)pd;
+            int seq = out->n_expanded++;
+            if (order && seq < order_cap) order[seq] = cell;
+            out->order_digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell);
+            batch[nb++] = cell;
+            if (cell == goal_cell) { status = DMPP_G_FOUND; out->path_cost = fcur; }
+            else if (out->n_expanded >= c->max_expansions) status = DMPP_G_LIMIT;
+        }
+        tail[b] -= take;
+        if (status >= 0) break;
+        /* expand phase */
+        for (int i = 0; i < nb && status < 0; i++) {
+            int cell = batch[i];
+            int x = cell % W, y = cell / W;
+            int g = fcur - hfun(x, y, gx, gy);
+            for (int d = 0; d < 8; d++) {
+                int nx = x + DX[d], ny = y + DY[d];
+                if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+                int n = ny * W + nx;
+                if (closed[n]) continue;
+                int fn = g + ((d & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
+                int bb = (fn / 2) % 16;
+                if (tail[bb] >= cap) { status = DMPP_G_OVERFLOW; break; }
+                bucket[(size_t)bb * cap + tail[bb]++] = (uint32_t)n | ((uint32_t)d << 24);
+                out->n_pushed++;
+            }
         }
     }
     out->status = status;

@@ -235,6 +235,7 @@ def test_search_limits(dm, oracle):
         assert (gout_o["status"] == want).any(), (key, np.bincount(gout_o["status"]))
     # goal walled in: ring of obstacles around the goal -> NO_PATH; goal inside an obstacle -> GOAL_BLOCKED
     cfg = base.copy()
+    cfg["bucket_cap"] = 1 << 18            # a flood fill of the whole map stacks many duplicates
     sc2 = dm.gen_scenes(cfg, 12000, 4, 64, junction_every=0)
     for s in range(4):
         gx, gy = sc2["scene_in"]["goal"]["x"][s], sc2["scene_in"]["goal"]["y"][s]

@@ -89,21 +89,8 @@ def main():
         pl.set_scenes(sc)
         pl.set_state(sc["state"])
     else:
-        shards = None
-        if rank == 0:
-            shards = [dm.gen_scenes(cfg, r * n, n, n_obs, junction_every=8) for r in range(world)]
-        proto = dm.gen_scenes(cfg, 0, 1, n_obs)      # dtypes/shapes only
-        recv = {}
-        for k in keys:
-            per_scene = len(proto[k])
-            dt = proto[k].dtype
-            nbytes = per_scene * n * dt.itemsize if k not in ("obs_pool", "mot_pool") else max(n * n_obs, 1) * dt.itemsize
-            dst = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-            src = None
-            if rank == 0:
-                src = [torch.from_numpy(np.frombuffer(s[k].tobytes(), np.uint8).copy()).cuda() for s in shards]
-            dist.scatter(dst, src, src=0)
-            recv[k] = dst
+        from dmpp_amd_pkg import sharding
+        recv = sharding.scatter_scenes(dm, dist, torch, cfg, n, n_obs, rank, world, torch.device('cuda', local_rank))
         torch.cuda.synchronize()
         lib = pl.lib
         dm._check(lib.pp_set_scenes(pl.h, n, recv["scene_in"].data_ptr(), recv["lane_pool"].data_ptr(), n * 3 * dm.GEN_LANE_PTS,
@@ -138,10 +125,12 @@ def main():
     # ---- results gathered over RCCL (digest check on rank 0) ----
     gout = pl.get_grid_out()
     if dist is not None:
+        from dmpp_amd_pkg import sharding
         mine = torch.from_numpy(gout["order_digest"].astype(np.int64)).cuda()
-        allg = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, allg, dst=0)
+        allg = sharding.gather_results(dist, torch, mine, rank, world)
         torch.cuda.synchronize()
+        if rank == 0:
+            assert len(allg) == world and all(t.numel() == n for t in allg)
 
     # ---- p50 plan latency, batch = 1 (rank 0) ----
     p50_ms = None

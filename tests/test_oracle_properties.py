@@ -1,0 +1,181 @@
+"""CPU: properties of the oracle's build-defined parts (the CShare helpers and the grid engine),
+checked against independent brute-force formulations in numpy / pure Python."""
+import heapq
+
+import numpy as np
+import pytest
+
+DX = [1, 1, 0, -1, -1, -1, 0, 1]
+DY = [0, 1, 1, 1, 0, -1, -1, -1]
+
+
+@pytest.fixture(scope="module")
+def cfg(dm):
+    return dm.default_config(128)
+
+
+def _wavy(dm, n, rng):
+    p = np.zeros(n, dm.GlobalPoint2D)
+    p["x"] = np.cumsum(rng.uniform(0.3, 0.7, n))
+    p["y"] = 2.5 * np.sin(p["x"] / 7.0)
+    return p
+
+
+def test_search_obstacle_matches_bruteforce_definition(dm, oracle, cfg):
+    rng = np.random.default_rng(7)
+    eps = cfg["EPSILON"][0]
+    for _ in range(200):
+        n, m = int(rng.integers(2, 150)), int(rng.integers(0, 40))
+        p = _wavy(dm, n, rng)
+        o = np.zeros(m, dm.ObPoint)
+        o["x"], o["y"] = rng.uniform(-5, p["x"][-1] + 5, m), rng.uniform(-6, 6, m)
+        lo, hi = -float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 2))
+        r = oracle.SearchObstacle(cfg, p, o, lo, hi)
+        s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(p["x"]), np.diff(p["y"])))])
+        best = None
+        for j in range(m):
+            d2 = (o["x"][j] - p["x"]) ** 2 + (o["y"][j] - p["y"]) ** 2
+            bi = int(np.argmin(d2))
+            idx = n - 2 if bi == n - 1 else bi
+            ax, ay, bx, by = p["x"][idx], p["y"][idx], p["x"][idx + 1], p["y"][idx + 1]
+            if bi == 0 and (o["x"][j] - ax) * (bx - ax) + (o["y"][j] - ay) * (by - ay) < 0:
+                continue
+            if bi == n - 1 and (o["x"][j] - bx) * (bx - ax) + (o["y"][j] - by) * (by - ay) > 0:
+                continue
+            cross = (bx - ax) * (o["y"][j] - ay) - (by - ay) * (o["x"][j] - ax)
+            lat = abs(cross) / np.hypot(bx - ax, by - ay)
+            lat = 0.0 if lat < eps else (lat if cross > 0 else -lat)
+            if lo <= lat <= hi and (best is None or s[bi] < best[0]):
+                best = (s[bi], lat, j, bi)
+        if best is None:
+            assert r["flag"] == 0 and r["dis_lng"] == 999 and r["dis_lat"] == 999      # sentinel callers rely on
+        else:
+            assert r["flag"] == 1 and r["path_id"] == best[3]
+            assert r["dis_lng"] == pytest.approx(best[0], rel=1e-12) and r["dis_lat"] == pytest.approx(best[1], rel=1e-9, abs=1e-12)
+            assert r["ob"]["x"] == o["x"][best[2]]
+
+
+def test_helper_curves(dm, oracle, cfg):
+    rng = np.random.default_rng(8)
+    s, e = (3.0, 4.0, 30.0), (40.0, 12.0, 350.0)
+    b = oracle.BezierPlanning(cfg, s, e)
+    assert (b["x"][0], b["y"][0]) == (3.0, 4.0) and b["x"][-1] == pytest.approx(40.0) and b["y"][-1] == pytest.approx(12.0)
+    h0 = np.degrees(np.arctan2(b["y"][1] - b["y"][0], b["x"][1] - b["x"][0]))
+    h1 = np.degrees(np.arctan2(b["y"][-1] - b["y"][-2], b["x"][-1] - b["x"][-2])) % 360
+    assert h0 == pytest.approx(30.0, abs=0.5) and h1 == pytest.approx(350.0, abs=0.5)     # leaves/arrives along the headings
+    p = _wavy(dm, 77, rng)
+    m = oracle.MeanPoints(cfg, p)
+    seg = np.hypot(np.diff(m["x"]), np.diff(m["y"]))
+    assert m[0] == p[0] and m["x"][-1] == pytest.approx(p["x"][-1]) and seg.std() / seg.mean() < 0.02   # uniform spacing
+    for off in (-3.75, 0.9):
+        q = oracle.CreateNewPath(cfg, p, off)
+        d = np.hypot(q["x"] - p["x"], q["y"] - p["y"])
+        assert np.allclose(d, abs(off), rtol=1e-12)
+        # negative = left of the direction of travel (Decision.cpp:629 vs :667)
+        tx, ty = np.gradient(p["x"]), np.gradient(p["y"])
+        side = tx * (q["y"] - p["y"]) - ty * (q["x"] - p["x"])
+        assert (np.sign(side) == (1 if off < 0 else -1)).all()
+
+
+def test_rasterise_equals_bruteforce(dm, oracle, cfg):
+    rng = np.random.default_rng(9)
+    for _ in range(5):
+        o = np.zeros(12, dm.ObPoint)
+        o["x"], o["y"] = rng.uniform(-3, 35, 12), rng.uniform(-3, 35, 12)        # some straddle the border
+        o["radius"] = rng.uniform(0.3, 1.5, 12).astype(np.float32)
+        g = oracle.rasterise(cfg, (0.0, 0.0), o)
+        assert np.array_equal(g, oracle.rasterise(cfg, (0.0, 0.0), o, brute=True))
+        assert set(np.unique(g)) <= {0, 1}
+    assert not oracle.rasterise(cfg, (0.0, 0.0), o[:0]).any()
+
+
+def _dijkstra(grid, start, goal):
+    H, W = grid.shape
+    dist = {start: 0}
+    pq = [(0, start)]
+    while pq:
+        d, c = heapq.heappop(pq)
+        if c == goal:
+            return d
+        if d > dist[c]:
+            continue
+        x, y = c % W, c // W
+        for k in range(8):
+            nx, ny = x + DX[k], y + DY[k]
+            if 0 <= nx < W and 0 <= ny < H and not grid[ny, nx]:
+                nd = d + (14 if k & 1 else 10)
+                n = ny * W + nx
+                if nd < dist.get(n, 1 << 60):
+                    dist[n] = nd
+                    heapq.heappush(pq, (nd, n))
+    return None
+
+
+def test_grid_search_is_optimal_and_well_formed(dm, oracle, cfg):
+    """The batched LIFO bucket search returns a minimum-cost 8-connected path (checked against an
+    independent Dijkstra), each cell is expanded once, and the digest matches its definition."""
+    W = 128
+    sc = dm.gen_scenes(cfg, 40, 24, 24, junction_every=0)
+    found = 0
+    for s in range(24):
+        obs = sc["obs_pool"][s * 24:(s + 1) * 24]
+        grid = oracle.rasterise(cfg, (0.0, 0.0), obs)
+        si = sc["scene_in"][s]
+        st = oracle.cell_of(cfg, (0.0, 0.0), float(si["loc"]["globalpoint"]["x"]), float(si["loc"]["globalpoint"]["y"]))
+        go = oracle.cell_of(cfg, (0.0, 0.0), float(si["goal"]["x"]), float(si["goal"]["y"]))
+        out, order, path = oracle.grid_search(cfg, grid, st, go, order_cap=W * W)
+        status = int(out["status"][0])
+        g2 = grid.copy()
+        g2.reshape(-1)[st] = 0
+        ref = None if grid.reshape(-1)[go] else _dijkstra(g2, st, go)
+        if grid.reshape(-1)[go]:
+            assert status == dm.G_GOAL_BLOCKED
+            continue
+        if ref is None:
+            assert status == dm.G_NO_PATH
+            continue
+        found += 1
+        assert status == dm.G_FOUND and int(out["path_cost"][0]) == ref                      # optimal
+        assert len(set(order.tolist())) == len(order) == int(out["n_expanded"][0])              # closed once
+        assert path[0] == st and path[-1] == go
+        cost = 0
+        for a, b in zip(path[:-1], path[1:]):
+            dx, dy = b % W - a % W, b // W - a // W
+            assert max(abs(dx), abs(dy)) == 1 and not g2.reshape(-1)[b]
+            cost += 14 if dx and dy else 10
+        assert cost == ref
+        mix = lambda v: _mix64(v)
+        dig = sum(_mix64((k << 32) | int(c)) for k, c in enumerate(order)) & ((1 << 64) - 1)
+        assert dig == int(out["order_digest"][0])
+    assert found >= 12
+
+
+def _mix64(v):
+    M = (1 << 64) - 1
+    z = (v + 0x9e3779b97f4a7c15) & M
+    z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & M
+    z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & M
+    return z ^ (z >> 31)
+
+
+def test_scoring_prefers_clear_low_curvature_candidates(dm, oracle, cfg):
+    sc = dm.gen_scenes(cfg, 70, 16, 8, junction_every=0)
+    st = sc["state"].copy()
+    _, gout, _ = oracle.plan_tick_batch(cfg, sc, st)
+    for g in gout:
+        nc = int(g["n_candidates"])
+        cost = g["cand_cost"][:nc]
+        assert int(g["best_candidate"]) == int(np.argmin(cost))                      # argmin, ties to the lowest index
+        assert (g["cand_col"][:nc] >= 0).all() and (g["cand_prog"][:nc] >= 0).all() and (g["cand_prog"][:nc] <= 1).all()
+        assert nc == (17 if g["status"] == dm.G_FOUND else 16)                        # the grid path joins only when found
+        assert np.isfinite(g["best_path"]["x"]).all()
+
+
+def test_dynamic_obstacles_move_with_the_tick(dm, oracle):
+    cfg = dm.default_config(128)
+    cfg["dynamic_obstacles"] = 1
+    sc = dm.gen_scenes(cfg, 5, 1, 8, junction_every=0)
+    o3 = oracle.effective_obstacles(cfg, sc["obs_pool"], sc["mot_pool"], 3)
+    assert np.allclose(o3["x"], sc["obs_pool"]["x"] + sc["mot_pool"]["vx"] * 0.3, rtol=1e-15)
+    cfg["dynamic_obstacles"] = 0
+    assert oracle.effective_obstacles(cfg, sc["obs_pool"], sc["mot_pool"], 3).tobytes() == sc["obs_pool"].tobytes()

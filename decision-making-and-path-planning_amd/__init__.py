@@ -127,9 +127,11 @@ def load_library(path=None):
     lib.pp_get_grid.argtypes = [vp, ci, vp]
     lib.pp_get_order.argtypes = [vp, ci, vp, ci]
     lib.pp_get_path.argtypes = [vp, ci, vp, ci]
+    lib.pp_get_refpath.argtypes = [vp, ci, vp, ci]
     lib.pp_plan_tick_batch.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp]
     lib.pp_search_obstacle_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.pp_geom_batch.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+    lib.pp_scalar_stage.argtypes = [vp, ci, vp, ci, vp, vp, ci]
     lib.pp_bezier.argtypes = [vp, _P3, _P3, vp, ci]
     lib.pp_mean_points.argtypes = [vp, vp, ci, vp, ci]
     lib.pp_create_new_path.argtypes = [vp, vp, ci, C.c_double, vp]
@@ -265,6 +267,11 @@ class Planner:
         _check(self.lib.pp_get_path(self.h, scene, _ptr(out), n))
         return out[:n]
 
+    def get_refpath(self, scene, n):
+        out = np.zeros(max(n, 1), GlobalPoint2D)
+        _check(self.lib.pp_get_refpath(self.h, scene, _ptr(out), n))
+        return out[:n]
+
     def plan_tick_batch(self, sc, state, with_motion=True, want_grid=True):
         """One-shot upload + tick + download (pp_plan_tick_batch). Updates `state` in place."""
         n = len(sc["scene_in"])
@@ -289,6 +296,12 @@ class Planner:
         n = len(a)
         out = np.zeros(n, np.float64)
         _check(self.lib.pp_geom_batch(self.h, op, n, _ptr(a), _ptr(b), _ptr(c), _ptr(out)))
+        return out
+
+    def scalar_stage(self, op, args, last_Bpoints=None, n_out=3):
+        a = np.asarray(args, np.float64).copy()
+        out = np.zeros(n_out, np.float64)
+        _check(self.lib.pp_scalar_stage(self.h, op, _ptr(a), len(a), _ptr(last_Bpoints), _ptr(out), n_out))
         return out
 
     def bezier(self, start, end, n=PATH_POINTS):

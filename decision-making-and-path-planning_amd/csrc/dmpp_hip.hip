@@ -360,6 +360,13 @@ int pp_get_order(pp_handle h, int scene, int32_t* order, int cap)
     if (cap > h->caps.order_cap) cap = h->caps.order_cap;
     return fetch(h, order, h->d_order + (size_t)scene * h->caps.order_cap, (size_t)cap * sizeof(int32_t));
 }
+int pp_get_refpath(pp_handle h, int scene, GlobalPoint2D* pts, int cap)
+{
+    if (!h || !pts) return fail(PP_ERR_ARG, "null argument");
+    if (scene < 0 || scene >= h->n_scenes) return fail(PP_ERR_ARG, "scene out of range");
+    if (cap > DMPP_MAX_REFPATH) cap = DMPP_MAX_REFPATH;
+    return fetch(h, pts, h->d_dec_ref + (size_t)scene * DMPP_MAX_REFPATH, (size_t)cap * sizeof(GlobalPoint2D));
+}
 int pp_get_path(pp_handle h, int scene, int32_t* path, int cap)
 {
     if (!h || !path || !h->d_path) return fail(PP_ERR_ARG, "no path buffer");
@@ -411,7 +418,30 @@ __global__ void k_geom_batch(PlannerConfig c, int op, int n, const GlobalPoint2D
     if (i >= n) return;
     if (op == 0) out[i] = GetLatDis(c, a[i], b[i], cc[i]);
     else if (op == 1) out[i] = GetRoadAngle(c, a[i], b[i]);
-    else out[i] = GetAngleErr(a[i].x, a[i].y);
+    else if (op == 2) out[i] = GetAngleErr(a[i].x, a[i].y);
+    else if (op == 3) out[i] = CalcDistance(a[i], b[i]);
+    else if (op == 4) out[i] = c.wgs_lat0 + a[i].y * c.wgs_deg_per_m_lat;      // GlobalToWGS84 .lat
+    else out[i] = c.wgs_lng0 + a[i].x * c.wgs_deg_per_m_lng;                   // GlobalToWGS84 .lng
+}
+
+// One scalar stage of the planning tick on explicit arguments (the CPlanning methods of the same name).
+//   op 0 UpdatePlanJudge : in = {last_behavior, behavior, pos, path_lat_dis, path_dir_err, remain_dis} -> out = {afresh, cause}
+//   op 1 SpeedPlanning   : in = {pos, ob_flag, mindist_lon, faraim_dis, velocity_expect, brake_speed, acc_flag, des_acc} -> out = {brake_speed, acc_flag, des_acc}
+//   op 2 CalculateRadius : in = {path_near_id, path_front_near_id}, pts = last_Bpoints[200] -> out = {radius}
+__global__ void k_scalar_stage(PlannerConfig c, int op, const double* in, const GlobalPoint2D* pts, double* out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (op == 0) {
+        int cause = 0;
+        const int afresh = d_UpdatePlanJudge(c, (int)in[0], (int)in[1], (int)in[2], in[3], in[4], in[5], cause);
+        out[0] = afresh; out[1] = cause;
+    } else if (op == 1) {
+        double bs = in[5], da = in[7]; int af = (int)in[6];
+        d_SpeedPlanning((int)in[0], (int)in[1], in[2], (float)in[3], in[4], bs, af, da);
+        out[0] = bs; out[1] = af; out[2] = da;
+    } else {
+        out[0] = d_CalculateRadius(pts, (int)in[0], (int)in[1]);
+    }
 }
 
 __global__ void k_bezier(PlannerConfig c, GlobalPoint3D s, GlobalPoint3D e, GlobalPoint2D* out, int n)
@@ -484,8 +514,8 @@ int pp_search_obstacle_batch(pp_handle h, int nq, const GlobalPoint2D* paths, co
 
 int pp_geom_batch(pp_handle h, int op, int n, const GlobalPoint2D* a, const GlobalPoint2D* b, const GlobalPoint2D* c3, double* out)
 {
-    if (!h || !a || !out || op < 0 || op > 2) return fail(PP_ERR_ARG, "bad argument");
-    if ((op <= 1 && !b) || (op == 0 && !c3)) return fail(PP_ERR_ARG, "missing operand");
+    if (!h || !a || !out || op < 0 || op > 5) return fail(PP_ERR_ARG, "bad argument");
+    if (((op <= 1 || op == 3) && !b) || (op == 0 && !c3)) return fail(PP_ERR_ARG, "missing operand");
     if (n <= 0) return PP_OK;
     HIP_TRY(hipSetDevice(h->device));
     const size_t pb = al256((size_t)n * sizeof(GlobalPoint2D));
@@ -498,6 +528,23 @@ int pp_geom_batch(pp_handle h, int op, int n, const GlobalPoint2D* a, const Glob
                        (const GlobalPoint2D*)(d + pb), (const GlobalPoint2D*)(d + 2 * pb), (double*)(d + 3 * pb));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d + 3 * pb, (size_t)n * 8, hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PP_OK;
+}
+
+int pp_scalar_stage(pp_handle h, int op, const double* in, int n_in, const GlobalPoint2D* last_Bpoints, double* out, int n_out)
+{
+    if (!h || !in || !out || op < 0 || op > 2 || n_in < 1 || n_in > 8 || n_out < 1 || n_out > 4) return fail(PP_ERR_ARG, "bad argument");
+    if (op == 2 && !last_Bpoints) return fail(PP_ERR_ARG, "CalculateRadius needs the 200 path points");
+    HIP_TRY(hipSetDevice(h->device));
+    int r = need_scratch(h, 4096 + DMPP_PATH_POINTS * sizeof(GlobalPoint2D)); if (r) return r;
+    char* d = (char*)h->d_scratch;
+    HIP_TRY(hipMemcpyAsync(d, in, (size_t)n_in * 8, hipMemcpyDefault, h->stream));
+    if (op == 2) HIP_TRY(hipMemcpyAsync(d + 4096, last_Bpoints, DMPP_PATH_POINTS * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    hipLaunchKernelGGL(dmpp::k_scalar_stage, dim3(1), dim3(64), 0, h->stream, h->cfg, op, (const double*)d,
+                       (const GlobalPoint2D*)(d + 4096), (double*)(d + 2048));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d + 2048, (size_t)n_out * 8, hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PP_OK;
 }

@@ -39,6 +39,46 @@ k_effective_obstacles(PlannerConfig c, int n_scenes, const SceneIn* __restrict__
     }
 }
 
+// ---- scalar stages of the planning tick, shared by k_planning and the stand-alone stage operator ----
+// UpdatePlanJudge, Planning.cpp:797-832 (reads the members path_lat_dis / path_dir_err / remain_dis)
+__device__ inline int d_UpdatePlanJudge(const PlannerConfig& c, int last_behavior, int behavior, int pos,
+                                        double path_lat_dis, double path_dir_err, double remain_dis, int& cause)
+{
+    cause = 0;
+    if (last_behavior != behavior) { cause = 1; return 1; }
+    if (fabs(path_lat_dis) > 0.2) { cause = 2; return 1; }
+    if (fabs(path_dir_err) > 45) { cause = 3; return 1; }
+    if ((pos == 0) && remain_dis < c.ROAD_REMAIN_DISTANCE) { cause = 4; return 1; }
+    else if (pos != 0 && remain_dis < c.INTER_REMAIN_DISTANCE) { cause = 4; return 1; }
+    return 0;
+}
+// SpeedPlanning, Planning.cpp:888-990 (three identical cases; other pos values leave the outputs alone)
+__device__ inline void d_SpeedPlanning(int pos, int ob_flag, double lon, float faraim, double velocity_expect,
+                                       double& brakespeed, int& acc_flag, double& des_acc)
+{
+    if (pos == 0 || pos == 1 || pos == 2) {
+        if (ob_flag) {
+            if (lon - 4 > 9) { brakespeed = 3 + (lon - 9) / (faraim - 9) * (velocity_expect - 3); acc_flag = 0; des_acc = 0; }
+            else if (lon - 4 > 5) { brakespeed = 3; acc_flag = 0; des_acc = 0; }
+            else { brakespeed = 0; acc_flag = 1; des_acc = -3; }
+        } else { brakespeed = velocity_expect; acc_flag = 0; des_acc = 0; }
+    }
+}
+// CalculateRadius, Planning.cpp:1000-1019 (ids fenced to [0,199]; a NaN sinA gives a NaN radius as in the reference)
+__device__ inline double d_CalculateRadius(const GlobalPoint2D* last, int near_id, int front_id)
+{
+    const int nid = clampi(near_id, 0, 199), f2 = clampi(front_id, 0, 199);
+    const unsigned mnum = (unsigned)round((double)((nid + f2) / 2));
+    const GlobalPoint2D a = last[nid], mm = last[mnum], f = last[f2];
+    double dis1 = sqrt((a.x - mm.x) * (a.x - mm.x) + (a.y - mm.y) * (a.y - mm.y));
+    double dis2 = sqrt((mm.x - f.x) * (mm.x - f.x) + (mm.y - f.y) * (mm.y - f.y));
+    double dis3 = sqrt((a.x - f.x) * (a.x - f.x) + (a.y - f.y) * (a.y - f.y));
+    double dis = dis1 * dis1 + dis2 * dis2 - dis3 * dis3;
+    double cosA = dis / (2 * dis1 * dis2);
+    double sinA = sqrt(1 - cosA * cosA);
+    return (sinA < 0.001) ? 1000 : 0.5 * dis3 / sinA;
+}
+
 // Block-wide arc-length walk shared by every branch of SearchAimPoint (Planning.cpp:410-432,
 // 448-469,478-499,507-538): accumulate |P[i+1]-P[i]| for i = i0 .. iend-1 in index order and
 // stop at the first i with sum - 4 > faraim.  Segment lengths are computed 256 at a time in
@@ -491,12 +531,8 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         const double pt_dir = GetRoadAngle(c, pt, pt_next);
         const double dir_err = GetAngleErr(pt_dir, ego.dir);
         // ---- UpdatePlanJudge, Planning.cpp:797-832 ----
-        int cause = 0, afresh = 0;
-        if (st.his_behavior != dec.behavior) { cause = 1; afresh = 1; }
-        else if (fabs(lat) > 0.2) { cause = 2; afresh = 1; }
-        else if (fabs(dir_err) > 45) { cause = 3; afresh = 1; }
-        else if ((pos == 0) && remain < c.ROAD_REMAIN_DISTANCE) { cause = 4; afresh = 1; }
-        else if (pos != 0 && remain < c.INTER_REMAIN_DISTANCE) { cause = 4; afresh = 1; }
+        int cause = 0;
+        int afresh = d_UpdatePlanJudge(c, st.his_behavior, dec.behavior, pos, lat, dir_err, remain, cause);
         if (c.force_replan && !afresh) { afresh = 1; cause = 5; }
         st.path_lat_dis = lat; st.path_dir_err = dir_err; st.remain_dis = remain;
         st.path_near_id = mid; st.path_front_near_id = fid;
@@ -507,18 +543,7 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         int na = aim_far.Aim_id; if (na > 200) na = 200; if (na > dec.refpath_n) na = dec.refpath_n; if (na < 0) na = 0;
         sh.na = na;
         // CalculateRadius, Planning.cpp:1000-1019: runs on the OLD path (called at :199, path saved at :217)
-        {
-            const int nid = clampi(mid, 0, 199), f2 = clampi(fid, 0, 199);
-            const unsigned mnum = (unsigned)round((double)((nid + f2) / 2));
-            const GlobalPoint2D a = sh.last[nid], mm = sh.last[mnum], f = sh.last[f2];
-            double dis1 = sqrt((a.x - mm.x) * (a.x - mm.x) + (a.y - mm.y) * (a.y - mm.y));
-            double dis2 = sqrt((mm.x - f.x) * (mm.x - f.x) + (mm.y - f.y) * (mm.y - f.y));
-            double dis3 = sqrt((a.x - f.x) * (a.x - f.x) + (a.y - f.y) * (a.y - f.y));
-            double dis = dis1 * dis1 + dis2 * dis2 - dis3 * dis3;
-            double cosA = dis / (2 * dis1 * dis2);
-            double sinA = sqrt(1 - cosA * cosA);
-            po.result.radius = (sinA < 0.001) ? 1000 : 0.5 * dis3 / sinA;
-        }
+        po.result.radius = d_CalculateRadius(sh.last, mid, fid);
     }
     __syncthreads();
 
@@ -555,13 +580,7 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         const SoResult r = sh.so;
         double brakespeed = st.brakespeed, des_acc = st.des_acc; int acc_flag = st.acc_flag;
         const double lon = r.dis_lng;
-        if (pos == 0 || pos == 1 || pos == 2) {
-            if (r.flag) {
-                if (lon - 4 > 9) { brakespeed = 3 + (lon - 9) / (faraim - 9) * (dec.velocity_expect - 3); acc_flag = 0; des_acc = 0; }
-                else if (lon - 4 > 5) { brakespeed = 3; acc_flag = 0; des_acc = 0; }
-                else { brakespeed = 0; acc_flag = 1; des_acc = -3; }
-            } else { brakespeed = dec.velocity_expect; acc_flag = 0; des_acc = 0; }
-        }
+        d_SpeedPlanning(pos, r.flag, lon, faraim, dec.velocity_expect, brakespeed, acc_flag, des_acc);
         st.brakespeed = brakespeed; st.des_acc = des_acc; st.acc_flag = acc_flag;
         po.show.afresh_cause = st.afresh_cause; po.show.near_ob_dist = lon; po.show.planspeed = brakespeed;
         po.show.planacc = des_acc; po.show.trafficlight = dec.light;

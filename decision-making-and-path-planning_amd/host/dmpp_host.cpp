@@ -1,0 +1,248 @@
+// dmpp_host.cpp — the C++ class surface over libdmpp.so.  No arithmetic of the planning path is done
+// here: every method marshals its arguments into the C-ABI and reads the result back.
+#include "dmpp_decision.hpp"
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+
+namespace {
+pp_handle g_handle = nullptr;
+PlannerConfig g_cfg;
+bool g_cfg_init = false;
+DmppStatus g_status;
+
+// pools of a single scene in the layout pp_plan_tick_batch expects
+struct OneScene {
+    SceneIn in{};
+    vector<GlobalPoint3D> lanes;
+    vector<GlobalPoint2D> ref;
+    vector<ObPoint> obs;
+};
+void build_scene(const LaneMap& m, const LocationOut& loc, const DecisionOut& dec, const vector<GlobalPoint2D>& ref,
+                 const vector<ObPoint>& obs, int stub_attribute, OneScene& s)
+{
+    std::memset(&s.in, 0, sizeof(s.in));
+    s.in.loc = loc; s.in.dec = dec;
+    s.lanes.clear();
+    s.in.lanes.cur_off = 0; s.in.lanes.cur_n = (int)m.cur.size();
+    s.lanes.insert(s.lanes.end(), m.cur.begin(), m.cur.end());
+    s.in.lanes.left_off = (int)s.lanes.size(); s.in.lanes.left_n = (int)m.left.size();
+    s.lanes.insert(s.lanes.end(), m.left.begin(), m.left.end());
+    s.in.lanes.right_off = (int)s.lanes.size(); s.in.lanes.right_n = (int)m.right.size();
+    s.lanes.insert(s.lanes.end(), m.right.begin(), m.right.end());
+    if (s.lanes.empty()) s.lanes.push_back(GlobalPoint3D{0, 0, 0});
+    s.in.lanes.lane_sum = m.lane_sum; s.in.lanes.lanechg_attribute = m.lanechg_attribute; s.in.lanes.lane_width = m.lane_width;
+    s.ref = ref; if (s.ref.size() > DMPP_MAX_REFPATH) s.ref.resize(DMPP_MAX_REFPATH);
+    s.in.ref_off = 0; s.in.ref_n = (int)s.ref.size(); s.in.dec.refpath_n = (int)s.ref.size();
+    if (s.ref.empty()) s.ref.push_back(GlobalPoint2D{0, 0});
+    s.obs = obs; s.in.obs_off = 0; s.in.obs_n = (int)obs.size();
+    if (s.obs.empty()) s.obs.push_back(ObPoint{0, 0, 0, 0});
+    s.in.stub_attribute = stub_attribute;
+    s.in.goal = GlobalPoint2D{loc.globalpoint.x, loc.globalpoint.y};
+}
+int run_scene(OneScene& s, SceneState& st, PlanOut& out, GridOut* grid, bool decision_stage)
+{
+    pp_handle h = CShare::Device();
+    if (!h) return PP_ERR_HIP;
+    PlannerConfig c = CShare::Config();
+    c.decision_stage = decision_stage ? 1 : 0;
+    if (!grid) c.grid_stage = 0;
+    int rc = pp_set_config(h, &c);
+    if (rc) return rc;
+    return pp_plan_tick_batch(h, 1, &s.in, s.obs.data(), nullptr, (int)s.obs.size(), s.lanes.data(), (int)s.lanes.size(),
+                              s.ref.data(), (int)s.ref.size(), &st, &out, grid);
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------- CShare
+PlannerConfig& CShare::Config()
+{
+    if (!g_cfg_init) { pp_default_config(&g_cfg, 512, 512); g_cfg_init = true; }
+    return g_cfg;
+}
+DmppStatus& CShare::LastStatus() { return g_status; }
+void CShare::note(int rc) { g_status.code = rc; g_status.text = rc ? pp_last_error() : ""; }
+pp_handle CShare::Device()
+{
+    if (!g_handle) {
+        PlannerCaps caps{};
+        caps.max_scenes = 1; caps.max_obs_total = 4096; caps.max_lane_pts_total = 1 << 16; caps.max_ref_pts_total = DMPP_MAX_REFPATH;
+        const char* dv = std::getenv("DMPP_DEVICE");
+        note(pp_create(&Config(), dv ? std::atoi(dv) : 0, &caps, &g_handle));
+    }
+    return g_handle;
+}
+void CShare::BezierPlanning(GlobalPoint3D start, GlobalPoint3D end, GlobalPoint2D out[], int n)
+{ note(pp_bezier(Device(), start, end, out, n)); }
+void CShare::MeanPoints(GlobalPoint2D in[], int n_in, GlobalPoint2D out[], int n_out)
+{ note(pp_mean_points(Device(), in, n_in, out, n_out)); }
+bool CShare::SearchObstacle(vector<GlobalPoint2D> path, vector<ObPoint> obs, double lat_lo, double lat_hi,
+                            double& dis_lat, double& dis_lng, ObPoint& ob, WORD& path_id)
+{
+    int32_t poff[2] = {0, (int32_t)path.size()}, ooff[2] = {0, (int32_t)obs.size()};
+    Path_Obs r{};
+    GlobalPoint2D dp{}; ObPoint dob{};
+    note(pp_search_obstacle_batch(Device(), 1, path.empty() ? &dp : path.data(), poff, obs.empty() ? &dob : obs.data(), ooff,
+                                  &lat_lo, &lat_hi, &r));
+    dis_lat = r.Ob_Pose.dis_lat; dis_lng = r.Ob_Pose.dis_lng; ob = r.Ob_Attr; path_id = (WORD)r.Ob_Pathid;
+    return r.Obs_flag != 0;
+}
+vector<GlobalPoint2D> CShare::CreateNewPath(vector<GlobalPoint2D> path, double offset)
+{
+    vector<GlobalPoint2D> out(path.size());
+    if (!path.empty()) note(pp_create_new_path(Device(), path.data(), (int)path.size(), offset, out.data()));
+    return out;
+}
+double CShare::CalcDistance(GlobalPoint2D a, GlobalPoint2D b)
+{ double v = 0; note(pp_geom_batch(Device(), 3, 1, &a, &b, nullptr, &v)); return v; }
+double CShare::CalcGlobalDir(GlobalPoint2D a, GlobalPoint2D b)
+{ double v = 0; note(pp_geom_batch(Device(), 1, 1, &a, &b, nullptr, &v)); return v; }
+GPSPoint2D CShare::GlobalToWGS84(GlobalPoint2D p)
+{
+    GPSPoint2D g{};
+    note(pp_geom_batch(Device(), 4, 1, &p, nullptr, nullptr, &g.lat));
+    note(pp_geom_batch(Device(), 5, 1, &p, nullptr, nullptr, &g.lng));
+    return g;
+}
+int CShare::NearestId(GlobalPoint2D p, vector<GlobalPoint2D> path)
+{   // the argmin loop of Planning.cpp:640-650 (first minimum); distances from the device
+    if (path.empty()) return 0;
+    vector<GlobalPoint2D> a(path.size(), p);
+    vector<double> d(path.size());
+    note(pp_geom_batch(Device(), 3, (int)path.size(), a.data(), path.data(), nullptr, d.data()));
+    return (int)(std::min_element(d.begin(), d.end()) - d.begin());
+}
+double CShare::LatDis(GlobalPoint2D p, GlobalPoint2D a, GlobalPoint2D b)
+{ double v = 0; note(pp_geom_batch(Device(), 0, 1, &p, &a, &b, &v)); return v; }
+
+// ------------------------------------------------------------------------------------- CPlanning
+CPlanning::CPlanning() { Reset(); }
+CPlanning& CPlanning::Instance() { static CPlanning thePlanning; return thePlanning; }
+BYTE CPlanning::startCPlanningThread() { return Device() ? 1 : 0; }
+void CPlanning::Reset()
+{
+    pp_init_state(&m_state, 1);
+    his_behavior = 1; path_near_id = path_front_near_id = 0;
+}
+
+void CPlanning::tick(const DecisionOutV& dec, const LocationOut& loc, const vector<ObPoint>& obs, SceneState& st,
+                     PlanOut& out, GridOut* grid, bool decision_stage)
+{
+    OneScene s;
+    build_scene(m_map, loc, dec, dec.refpath, obs, 0, s);
+    note(run_scene(s, st, out, grid, decision_stage));
+}
+
+void CPlanning::plan(const DecisionOutV& decision, const LocationOut& location, const VehStatus&, const vector<ObPoint>& obstacles,
+                     PlanningOut& result, PlanningStatus& show, GlobalPoint2D road_points[], GridOut* grid)
+{
+    PlanOut out{};
+    m_state.his_behavior = his_behavior;
+    tick(decision, location, obstacles, m_state, out, grid, false);
+    result = out.result; show = out.show;
+    if (road_points) std::memcpy(road_points, out.road_points, sizeof(out.road_points));
+    // mirror the public members the reference exposes (Planning.h:42-52)
+    path_lat_dis = m_state.path_lat_dis; afresh_planning = m_state.afresh_planning != 0; afresh_cause = m_state.afresh_cause;
+    remain_dis = m_state.remain_dis; path_dir_err = m_state.path_dir_err; path_near_id = m_state.path_near_id;
+    path_front_near_id = m_state.path_front_near_id; his_behavior = m_state.his_behavior; brakespeed = m_state.brakespeed;
+    acc_flag = m_state.acc_flag != 0; des_acc = m_state.des_acc;
+    faraim_dis = m_state.faraim_dis; nearaim_dis = m_state.nearaim_dis;
+    aimpoint_far = m_state.aimpoint_far; aimpoint_near = m_state.aimpoint_near;
+}
+
+// The stage methods below run the device tick on a SCRATCH copy of the state and return the stage's own
+// outputs (each of these stages stores its outputs in SceneState untouched by later stages).
+void CPlanning::Calculate_aim_dis(DecisionOutV dec, LocationOut loc, VehStatus, FLOAT& far_, FLOAT& near_)
+{
+    SceneState st = m_state; PlanOut out{};
+    tick(dec, loc, {}, st, out, nullptr, false);
+    far_ = st.faraim_dis; near_ = st.nearaim_dis;
+    faraim_dis = far_; nearaim_dis = near_;           // the reference writes the members (Planning.cpp:118)
+}
+void CPlanning::SearchAimPoint(DecisionOutV dec, LocationOut loc, VehStatus, AimPoint& far_, AimPoint& near_)
+{
+    SceneState st = m_state; PlanOut out{};
+    st.aimpoint_far = far_; st.aimpoint_near = near_;  // branches that assign nothing keep the caller's values
+    tick(dec, loc, {}, st, out, nullptr, false);
+    far_ = st.aimpoint_far; near_ = st.aimpoint_near;
+}
+void CPlanning::InitialPlanning(DecisionOutV, LocationOut loc, VehStatus, const AimPoint aimpoint_far, const AimPoint,
+                                GlobalPoint2D Bezier_points[])
+{ BezierPlanning(loc.globalpoint, aimpoint_far.Aim_point, Bezier_points, DMPP_PATH_POINTS); }           // Planning.cpp:596-611
+void CPlanning::GetVhclLocalState(LocationOut loc, const GlobalPoint2D last_Bpoints[], double& mindist_lat, double& dir_err,
+                                  int& mindist_id, int& front_mindist_id, double& remain)
+{
+    SceneState st = m_state; PlanOut out{};
+    std::memcpy(st.last_Bpoints, last_Bpoints, sizeof(st.last_Bpoints));
+    st.count = 1;                                      // not the first tick: no InitialPlanning
+    st.path_near_id = mindist_id;
+    DecisionOutV dec; dec.behavior = st.his_behavior; dec.target_lanenum = loc.lane_num;
+    tick(dec, loc, {}, st, out, nullptr, false);
+    mindist_lat = st.path_lat_dis; dir_err = st.path_dir_err; mindist_id = st.path_near_id;
+    front_mindist_id = st.path_front_near_id; remain = st.remain_dis;
+}
+bool CPlanning::UpdatePlanJudge(const DecisionOutV dec, const LocationOut loc, const int last_behavior, int& afreshcause)
+{
+    const double in[6] = {(double)last_behavior, (double)dec.behavior, (double)loc.pos, path_lat_dis, path_dir_err, remain_dis};
+    double out[2] = {0, 0};
+    note(pp_scalar_stage(Device(), 0, in, 6, nullptr, out, 2));
+    afreshcause = (int)out[1];
+    return out[0] != 0;
+}
+void CPlanning::PathPlanning(const DecisionOutV dec, int, LocationOut loc, const AimPoint aimpoint_far, const AimPoint,
+                             GlobalPoint2D road_points[])
+{   // Planning.cpp:845-877
+    if (loc.pos == 0) BezierPlanning(loc.globalpoint, aimpoint_far.Aim_point, road_points, DMPP_PATH_POINTS);
+    else if (loc.pos == 1 || loc.pos == 2) {
+        int na = std::min(std::min(aimpoint_far.Aim_id, DMPP_PATH_POINTS), (int)dec.refpath.size());
+        if (na < 0) na = 0;
+        vector<GlobalPoint2D> ref(dec.refpath.begin(), dec.refpath.begin() + na);
+        GlobalPoint2D dummy{};
+        MeanPoints(ref.empty() ? &dummy : ref.data(), na, road_points, DMPP_PATH_POINTS);
+    } else std::memset(road_points, 0, sizeof(GlobalPoint2D) * DMPP_PATH_POINTS);
+}
+void CPlanning::SpeedPlanning(const bool ob_flag, const DecisionOutV dec, const LocationOut loc, const double mindist_lon,
+                              const double, const FLOAT far_, double& brake_speed, bool& accf, double& desacc)
+{
+    const double in[8] = {(double)loc.pos, ob_flag ? 1.0 : 0.0, mindist_lon, (double)far_, dec.velocity_expect, brake_speed,
+                          accf ? 1.0 : 0.0, desacc};
+    double out[3] = {0, 0, 0};
+    note(pp_scalar_stage(Device(), 1, in, 8, nullptr, out, 3));
+    brake_speed = out[0]; accf = out[1] != 0; desacc = out[2];
+}
+double CPlanning::GetLatDis(GlobalPoint2D cur_pt, GlobalPoint2D pt, GlobalPoint2D pt_next) { return LatDis(cur_pt, pt, pt_next); }
+double CPlanning::GetRoadAngle(GlobalPoint2D a, GlobalPoint2D b) { return CalcGlobalDir(a, b); }
+double CPlanning::GetAngleErr(double dir1, double dir2)
+{ GlobalPoint2D a{dir1, dir2}; double v = 0; note(pp_geom_batch(Device(), 2, 1, &a, nullptr, nullptr, &v)); return v; }
+double CPlanning::CalculateRadius()
+{
+    const double in[2] = {(double)path_near_id, (double)path_front_near_id};
+    double out[1] = {0};
+    note(pp_scalar_stage(Device(), 2, in, 2, m_state.last_Bpoints, out, 1));
+    return out[0];
+}
+
+// ------------------------------------------------------------------------------------- CDecision
+CDecision::CDecision() { Reset(); }
+CDecision& CDecision::Instance() { static CDecision theDecision; return theDecision; }
+BYTE CDecision::startCDecisionThread() { return Device() ? 1 : 0; }
+void CDecision::Reset() { pp_init_state(&m_state, 1); }
+
+DecisionOutV CDecision::decide(const LocationOut& location, const vector<ObPoint>& obstacles,
+                               const vector<GlobalPoint2D>& junction_polyline, int stub_attribute, Path_Obs around[6])
+{
+    OneScene s;
+    DecisionOut none{};
+    build_scene(m_map, location, none, junction_polyline, obstacles, stub_attribute, s);
+    if (m_state.tick == 0 && m_state.z_target_lanenum != location.lane_num) {
+        m_state.z_target_lanenum = location.lane_num; m_state.d_his_target_lanenum = location.lane_num;
+    }
+    PlanOut out{};
+    note(run_scene(s, m_state, out, nullptr, true));
+    DecisionOutV d;
+    static_cast<DecisionOut&>(d) = out.dec;
+    d.refpath.resize((size_t)std::max(out.dec.refpath_n, 0));
+    if (!d.refpath.empty()) note(pp_get_refpath(Device(), 0, d.refpath.data(), (int)d.refpath.size()));
+    if (around) std::memcpy(around, out.around, sizeof(out.around));
+    return d;
+}

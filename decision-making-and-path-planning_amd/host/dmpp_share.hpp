@@ -1,0 +1,61 @@
+// dmpp_share.hpp — C++ host surface, part 1: the types and the CShare base class.
+//
+// The reference's Share.h is not shipped; this header supplies what Planning.h:2 /
+// Decision.h:2 expect from it, on top of the C-ABI (include/dmpp_planner.h).  Every helper runs on the
+// GPU through libdmpp.so — there is no host implementation of the arithmetic.
+#pragma once
+#include <vector>
+#include "../../include/dmpp_planner.h"
+
+using std::vector;
+
+// Win32 scalar names the reference uses (stdafx.h is not shipped either)
+typedef unsigned char  BYTE;
+typedef unsigned short WORD;
+typedef unsigned long  DWORD;
+typedef unsigned int   UINT;
+typedef int            INT;
+typedef int            BOOL;
+typedef float          FLOAT;
+typedef double         DOUBLE;
+
+// VehStatus is copied around but never read on the path (Planning.cpp:106)
+struct VehStatus { double reserved[4]; };
+
+// DecisionOut as the reference builds it (Decision.cpp:187-196): the POD of the C-ABI plus the refpath vector
+struct DecisionOutV : public DecisionOut {
+    double period_max = 0, period_last = 0;
+    vector<GlobalPoint2D> refpath;
+    DecisionOutV() : DecisionOut{} {}
+};
+
+// planning_MapData[road][lane] as this boundary sees it: the current lane and its neighbours
+struct LaneMap {
+    vector<GlobalPoint3D> cur, left, right;
+    int lane_sum = 1, lanechg_attribute = 0;
+    double lane_width = 3.75;
+};
+
+// Raised into a flag instead of AfxMessageBox (Decision.cpp:514): the reference's methods return void
+struct DmppStatus { int code = 0; const char* text = ""; };
+
+class CShare {
+public:
+    // one GPU context per process for the single-scene class surface (device: env DMPP_DEVICE, default 0)
+    static pp_handle Device();
+    static PlannerConfig& Config();
+    static DmppStatus& LastStatus();
+
+    void   BezierPlanning(GlobalPoint3D start, GlobalPoint3D end, GlobalPoint2D out[], int n);       // Planning.cpp:606,863
+    void   MeanPoints(GlobalPoint2D in[], int n_in, GlobalPoint2D out[], int n_out);                 // Planning.cpp:872
+    bool   SearchObstacle(vector<GlobalPoint2D> path, vector<ObPoint> obs, double lat_lo, double lat_hi,
+                          double& dis_lat, double& dis_lng, ObPoint& ob, WORD& path_id);             // Planning.cpp:168
+    vector<GlobalPoint2D> CreateNewPath(vector<GlobalPoint2D> path, double offset);                  // Decision.cpp:629,942
+    double CalcDistance(GlobalPoint2D a, GlobalPoint2D b);                                           // Planning.cpp:509
+    double CalcGlobalDir(GlobalPoint2D a, GlobalPoint2D b);                                          // Planning.cpp:519
+    GPSPoint2D GlobalToWGS84(GlobalPoint2D p);                                                       // Planning.cpp:209
+    int    NearestId(GlobalPoint2D p, vector<GlobalPoint2D> path);                                   // Decision.cpp:1889
+    double LatDis(GlobalPoint2D p, GlobalPoint2D a, GlobalPoint2D b);                                // Decision.cpp:1895
+protected:
+    static void note(int rc);
+};

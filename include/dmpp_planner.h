@@ -88,6 +88,8 @@ int  pp_get_grid_out(pp_handle h, GridOut* out, int n_scenes);
 int  pp_get_grid(pp_handle h, int scene, uint8_t* grid);                 /* grid_w*grid_h bytes */
 int  pp_get_order(pp_handle h, int scene, int32_t* order, int cap);      /* needs caps.order_cap > 0 */
 int  pp_get_path(pp_handle h, int scene, int32_t* path, int cap);
+/* DecisionOut.refpath published by the decision stage (Decision.cpp:195); PlanOut.dec.refpath_n points are valid */
+int  pp_get_refpath(pp_handle h, int scene, GlobalPoint2D* pts, int cap);
 
 /* ---- one-shot batch call (the SURVEY §8b signature): upload, tick, download ---------------- */
 int  pp_plan_tick_batch(pp_handle h, int n_scenes, const SceneIn* in,
@@ -105,9 +107,19 @@ int  pp_search_obstacle_batch(pp_handle h, int n_queries,
                               const double* lat_lo, const double* lat_hi, Path_Obs* out);
 /* CPlanning::GetLatDis / GetRoadAngle / GetAngleErr (Planning.cpp:686-786), n independent items.
  * op 0: out = GetLatDis(a[i], b[i], c[i]);  op 1: out = GetRoadAngle(a[i], b[i]);
- * op 2: out = GetAngleErr(a[i].x, a[i].y). */
+ * op 2: out = GetAngleErr(a[i].x, a[i].y);  op 3: out = CShare::CalcDistance(a[i], b[i]);
+ * op 4 / 5: the .lat / .lng of CShare::GlobalToWGS84(a[i]) (Planning.cpp:209). */
 int  pp_geom_batch(pp_handle h, int op, int n, const GlobalPoint2D* a, const GlobalPoint2D* b,
                    const GlobalPoint2D* c, double* out);
+/* One scalar stage of the planning tick on explicit arguments:
+ *  op 0 CPlanning::UpdatePlanJudge (Planning.cpp:797-832): in = {last_behavior, behavior, pos, path_lat_dis,
+ *       path_dir_err, remain_dis} -> out = {afresh, cause}
+ *  op 1 CPlanning::SpeedPlanning (Planning.cpp:888-990): in = {pos, ob_flag, mindist_lon, faraim_dis,
+ *       velocity_expect, brake_speed, acc_flag, des_acc} -> out = {brake_speed, acc_flag, des_acc}
+ *  op 2 CPlanning::CalculateRadius (Planning.cpp:1000-1019): in = {path_near_id, path_front_near_id},
+ *       last_Bpoints = 200 points -> out = {radius} */
+int  pp_scalar_stage(pp_handle h, int op, const double* in, int n_in, const GlobalPoint2D* last_Bpoints,
+                     double* out, int n_out);
 /* CShare::BezierPlanning / MeanPoints / CreateNewPath on one polyline each (host pointers). */
 int  pp_bezier(pp_handle h, GlobalPoint3D start, GlobalPoint3D end, GlobalPoint2D* out, int n);
 int  pp_mean_points(pp_handle h, const GlobalPoint2D* in, int n_in, GlobalPoint2D* out, int n_out);

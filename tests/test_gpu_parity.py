@@ -264,3 +264,64 @@ def test_one_shot_batch_call_and_errors(dm, oracle):
     bad = cfg.copy(); bad["grid_w"] = 100
     with pytest.raises(dm.PlannerError):
         dm.Planner(bad, max_scenes=1)
+
+
+def test_scalar_stage_ops(dm, oracle):
+    """CPlanning::UpdatePlanJudge / SpeedPlanning / CalculateRadius as stand-alone device stages."""
+    cfg = dm.default_config(128)
+    pl = dm.Planner(cfg, max_scenes=1)
+    rng = np.random.default_rng(4)
+    dec, loc, st = np.zeros(1, dm.DecisionOut), np.zeros(1, dm.LocationOut), np.zeros(1, dm.SceneState)
+    for _ in range(60):
+        hb, b, pos = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(0, 4))
+        lat, derr, rem = float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-90, 90)), float(rng.uniform(0, 20))
+        dec["behavior"], loc["pos"] = b, pos
+        st["path_lat_dis"], st["path_dir_err"], st["remain_dis"] = lat, derr, rem
+        cause = np.zeros(1, np.int32)
+        want = oracle.L.orc_UpdatePlanJudge(cfg.ctypes.data, dec.ctypes.data, loc.ctypes.data, hb, st.ctypes.data, cause.ctypes.data)
+        got = pl.scalar_stage(0, [hb, b, pos, lat, derr, rem], n_out=2)
+        assert (int(got[0]), int(got[1])) == (want, int(cause[0]))
+        ob, lon, far, ve = int(rng.integers(0, 2)), float(rng.uniform(0, 30)), float(np.float32(rng.uniform(8, 40))), float(rng.uniform(3, 15))
+        dec["velocity_expect"] = ve
+        want = oracle.SpeedPlanning(ob, dec, loc, lon, 0.0, far, init=(1.5, 1, -0.5))
+        got = pl.scalar_stage(1, [pos, ob, lon, far, ve, 1.5, 1, -0.5], n_out=3)
+        assert (got[0], int(got[1]), got[2]) == want or (np.isinf(got[0]) and np.isinf(want[0]))
+    pts = np.zeros(200, dm.GlobalPoint2D)
+    pts["x"], pts["y"] = np.cumsum(rng.uniform(0.3, 0.7, 200)), np.cumsum(rng.uniform(-0.2, 0.2, 200))
+    for nid, fid in ((0, 8), (50, 58), (195, 203), (199, 207)):
+        got = pl.scalar_stage(2, [nid, fid], last_Bpoints=pts, n_out=1)[0]
+        want = oracle.CalculateRadius(pts, nid, fid)
+        assert got == want or (np.isnan(got) and np.isnan(want))
+    a, b = np.zeros(8, dm.GlobalPoint2D), np.zeros(8, dm.GlobalPoint2D)
+    a["x"], a["y"], b["x"], b["y"] = rng.uniform(0, 99, 8), rng.uniform(0, 99, 8), rng.uniform(0, 99, 8), rng.uniform(0, 99, 8)
+    assert np.array_equal(pl.geom_batch(3, a, b), np.hypot(a["x"] - b["x"], a["y"] - b["y"]) * 0 + np.sqrt((a["x"] - b["x"]) ** 2 + (a["y"] - b["y"]) ** 2))
+    assert np.array_equal(pl.geom_batch(4, a), cfg["wgs_lat0"][0] + a["y"] * cfg["wgs_deg_per_m_lat"][0])
+    assert np.array_equal(pl.geom_batch(5, a), cfg["wgs_lng0"][0] + a["x"] * cfg["wgs_deg_per_m_lng"][0])
+
+
+def test_decision_refpath_export(dm, oracle):
+    cfg = dm.default_config(128)
+    cfg["grid_stage"] = 0
+    sc = dm.gen_scenes(cfg, 33, 4, 8, junction_every=2)
+    pl = dm.Planner(cfg, max_scenes=4, max_obs_total=32)
+    st = sc["state"].copy()
+    plan, _ = pl.plan_tick_batch(sc, st, want_grid=False)
+    for s in range(4):
+        n = int(plan["dec"]["refpath_n"][s])
+        rp = pl.get_refpath(s, n)
+        assert n > 0 and np.isfinite(rp["x"]).all()
+        if sc["scene_in"]["loc"]["pos"][s] == 0:      # RefPath: the front corridor of the current lane (Decision.cpp:1813)
+            lo = int(sc["scene_in"]["lanes"]["cur_off"][s]) + int(sc["scene_in"]["loc"]["id"][s][0])
+            assert np.array_equal(rp["x"], sc["lane_pool"]["x"][lo:lo + n])
+
+
+def test_cpp_host_classes_example():
+    """The C++ CDecision/CPlanning surface (host/) driving the GPU through the C-ABI."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "decision-making-and-path-planning_amd", "host", "example_tick")
+    assert os.path.exists(exe), "build it with make -C decision-making-and-path-planning_amd/host"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout[-1500:], r.stderr[-500:])
+    assert r.returncode == 0 and "example ok" in r.stdout

@@ -43,7 +43,7 @@ struct pp_planner {
     SceneState* d_state = nullptr; PlanOut* d_plan = nullptr; GridOut* d_gout = nullptr;
     GlobalPoint2D* d_dec_ref = nullptr;
     // grid engine
-    uint8_t* d_grid = nullptr; uint8_t* d_parent = nullptr; uint32_t* d_bucket = nullptr;
+    uint8_t* d_grid = nullptr; uint16_t* d_pinfo = nullptr; uint32_t* d_closed = nullptr;
     int32_t* d_order = nullptr; int32_t* d_path = nullptr; uint32_t* d_gbm = nullptr;
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
@@ -71,8 +71,7 @@ int check_cfg(const PlannerConfig* c)
     if (c->grid_stage) {
         if (c->grid_w <= 0 || c->grid_h <= 0 || (c->grid_w % 32) != 0) return fail(PP_ERR_ARG, "grid_w must be a positive multiple of 32");
         if ((long long)c->grid_w * c->grid_h > (1ll << 24)) return fail(PP_ERR_ARG, "grid larger than 2^24 cells (cell index is 24 bits in an open-set entry)");
-        if (c->bucket_cap < 64 || c->max_path < 2) return fail(PP_ERR_ARG, "bucket_cap/max_path too small");
-        if ((long long)16 * c->bucket_cap < c->max_path) return fail(PP_ERR_ARG, "16*bucket_cap must be >= max_path");
+        if (c->bucket_cap < 16 || c->max_path < 2) return fail(PP_ERR_ARG, "bucket_cap/max_path too small");
         if (!(c->cell > 0)) return fail(PP_ERR_ARG, "cell size must be positive");
         if (c->n_lattice < 0 || c->n_lattice > DMPP_MAX_LATTICE - 1) return fail(PP_ERR_ARG, "n_lattice out of range");
     }
@@ -128,7 +127,7 @@ int setup_grid_launch(pp_planner* h)
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && v > 0) optin = (size_t)v;
     }
-    h->search_gbm = bm_bytes + 256 > (optin > lds_max ? optin : lds_max) || bm_bytes > 160u * 1024u - 256u;
+    h->search_gbm = bm_bytes + 8448 > (optin > lds_max ? optin : lds_max) || bm_bytes > 160u * 1024u - 8448u;   // + the open list
     h->search_lds = h->search_gbm ? 0 : (int)bm_bytes;
     if (!h->search_gbm && bm_bytes > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_search<false>),
@@ -180,8 +179,8 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
         h->grid_cells = (size_t)cfg->grid_w * cfg->grid_h;
         h->bucket_cap0 = cfg->bucket_cap; h->max_path0 = cfg->max_path;
         if ((r = dmalloc(&h->d_grid, ns * h->grid_cells))) return bail(r);
-        if ((r = dmalloc(&h->d_parent, ns * h->grid_cells))) return bail(r);
-        if ((r = dmalloc(&h->d_bucket, ns * 16 * (size_t)cfg->bucket_cap))) return bail(r);
+        if ((r = dmalloc(&h->d_pinfo, ns * h->grid_cells))) return bail(r);
+        if ((r = dmalloc(&h->d_closed, ns * (h->grid_cells / 32)))) return bail(r);
         if ((r = dmalloc(&h->d_path, ns * (size_t)cfg->max_path))) return bail(r);
         if (caps->order_cap > 0 && (r = dmalloc(&h->d_order, ns * (size_t)caps->order_cap))) return bail(r);
         if ((r = setup_grid_launch(h))) return bail(r);
@@ -201,7 +200,7 @@ int pp_destroy(pp_handle h)
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     void* bufs[] = { h->d_in, h->d_lane, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now, h->d_state, h->d_plan, h->d_gout,
-                     h->d_dec_ref, h->d_grid, h->d_parent, h->d_bucket, h->d_order, h->d_path, h->d_gbm, h->d_scratch };
+                     h->d_dec_ref, h->d_grid, h->d_pinfo, h->d_closed, h->d_order, h->d_path, h->d_gbm, h->d_scratch };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -214,7 +213,7 @@ int pp_set_config(pp_handle h, const PlannerConfig* cfg)
     int r = check_cfg(cfg); if (r) return r;
     if (cfg->grid_stage) {
         if (!h->d_grid) return fail(PP_ERR_STATE, "handle was created without the grid stage");
-        if ((size_t)cfg->grid_w * cfg->grid_h > h->grid_cells || cfg->bucket_cap > h->bucket_cap0 || cfg->max_path > h->max_path0)
+        if ((size_t)cfg->grid_w * cfg->grid_h > h->grid_cells || cfg->max_path > h->max_path0)
             return fail(PP_ERR_CAPACITY, "grid size / bucket_cap / max_path may not grow after pp_create");
     }
     HIP_TRY(hipSetDevice(h->device));
@@ -295,12 +294,13 @@ int pp_plan_tick(pp_handle h)
         }
         {
             Timed t(h, PP_K_SEARCH);
+            (void)hipMemsetAsync(h->d_closed, 0, (size_t)n * ((size_t)c.grid_w * c.grid_h / 8), h->stream);   // the closed bit sets
             if (h->search_gbm)
                 hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), 0, h->stream, c, n, h->caps.order_cap, h->d_in, h->d_grid,
-                                   h->d_bucket, h->d_parent, h->d_order, h->d_path, h->d_gout, h->d_gbm);
+                                   h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, h->d_gbm);
             else
                 hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap,
-                                   h->d_in, h->d_grid, h->d_bucket, h->d_parent, h->d_order, h->d_path, h->d_gout, (uint32_t*)nullptr);
+                                   h->d_in, h->d_grid, h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, (uint32_t*)nullptr);
         }
         {
             Timed t(h, PP_K_SCORE);

@@ -4,14 +4,11 @@
 //   k_rasterise : obstacle list -> u8 occupancy grid in HBM.  One workgroup per (scene, band of
 //                 rows): footprints are OR-ed into an LDS bit band, then the band is expanded to
 //                 bytes and written with 16-B-per-lane coalesced stores (HBM-write bound).
-//   k_search    : bucketed A* with LIFO levels, batches of 8.  ONE WAVE per scene: the u8 grid is read
-//                 once with 16-B-per-lane coalesced loads and packed into an LDS bitmap (blocked-
-//                 or-closed, 1 bit per cell); the open set is 16 stacks (f/2 mod 16): the top <= 96
-//                 entries of each in LDS, older ones spilled to HBM in 32-entry chunks, the heights
-//                 in a lane-spread VGPR.  A step takes the top 8 entries of the current level,
-//                 closes the open distinct ones and expands them on 8 x 8 lanes (node x direction);
-//                 successors are compacted per level with ballot + mbcnt prefix ranks, in batch
-//                 order then direction order.  No memory wait except LDS in the common step.
+//   k_search    : jump-point A*.  ONE WAVE per scene: the u8 grid is read once with 16-B-per-lane
+//                 coalesced loads and packed into an LDS obstacle bitmap; straight jumps are wave-wide
+//                 bit scans (32 cells per lane for E/W, one row per lane for N/S, ballot + ffs);
+//                 the open list is LDS resident (wave argmin pop, ballot + prefix-popcount
+//                 compaction); closed cells are a bit set in HBM.
 //   k_score     : lattice candidates (cubic Beziers to laterally shifted terminals + the grid
 //                 path) scored on collision / curvature / progress, 4 waves per scene.
 #pragma once
@@ -112,41 +109,106 @@ __device__ __forceinline__ uint32_t pack_nz4(uint32_t x)   // 4 bytes -> 4 bits 
     return (nz * 0x01020408u) >> 24;
 }
 
-struct SearchScratch {          // per scene, HBM
-    uint32_t* bucket;           // 16 * bucket_cap entries: cell | dir << 24
-    uint8_t*  parent;           // W*H arriving directions (written only for closed cells)
-    int32_t*  order;            // order_cap cells or null
-    int32_t*  path;             // max_path cells
+// G2: jump-point A* (specification: oracle/dmpp_grid_oracle.c).  ONE WAVE per scene.
+//   * the u8 grid is read once (16 B per lane, coalesced) and packed to an LDS bitmap of obstacles;
+//   * a straight jump is ONE wave-wide bit scan: for E/W every lane takes a 32-cell word of the row
+//     (2048 cells per instruction) and builds the stop mask  blocked | forced | goal  from the three
+//     rows with shifts; for N/S every lane takes one row (64 rows per pass); ballot + ffs finds the
+//     first stop.  Diagonal moves are single steps that go through the open list;
+//   * the open list lives in LDS in push order (f/2, cell|dir, run): pop = wave argmin on
+//     (f, latest push), dead slots are squeezed out with ballot + prefix-popcount compaction;
+//   * closed cells are a bit set in HBM (one returning atomicOr per pop) plus dir/run per closed cell
+//     for the path, which is a handful of runs rather than hundreds of single cells.
+constexpr int kOpenCap = DMPP_OPEN_CAP;
+
+template <bool GBM>
+struct Bits {
+    const uint32_t* bm; int W, H, WW;
+    // word w of row r, all ones outside the grid
+    __device__ __forceinline__ uint32_t word(int r, int w) const
+    {
+        if (r < 0 || r >= H || w < 0 || w >= WW) return 0xFFFFFFFFu;
+        return bm[r * WW + w];
+    }
+    __device__ __forceinline__ bool blk(int x, int y) const
+    {
+        if (x < 0 || y < 0 || x >= W || y >= H) return true;
+        return (bm[y * WW + (x >> 5)] >> (x & 31)) & 1u;
+    }
 };
 
-// blockDim = 64 (one wave).  GBM = false: the bitmap (W*H/8 bytes) is dynamic LDS — grids up to
-// 1024x1024.  GBM = true: the bitmap is a per-scene HBM/L2 scratch (2048x2048 = 512 KiB does not
-// fit the 160 KiB of LDS); same code, global loads/atomics instead of ds_ operations.
-constexpr int kWin = 96, kSpill = 32;   // LDS window per level: 8 kept + up to 64 pushed per step + one chunk
+// Run length of jump((x,y), E or W); 0 = none.  sgn = +1 (E) / -1 (W).  All 64 lanes take part.
+template <bool GBM>
+__device__ __forceinline__ int wave_jump_h(const Bits<GBM>& B, int x, int y, int sgn, int gx, int gy, int lane)
+{
+    const int wx = x >> 5, wi = wx + sgn * lane, nwi = wi + sgn;
+    const uint32_t B0 = B.word(y, wi), P = B.word(y + 1, wi), M = B.word(y - 1, wi);
+    const uint32_t Pw = B.word(y + 1, nwi), Mw = B.word(y - 1, nwi);
+    uint32_t Pn, Mn;
+    if (sgn > 0) { Pn = (P >> 1) | (Pw << 31); Mn = (M >> 1) | (Mw << 31); }
+    else         { Pn = (P << 1) | (Pw >> 31); Mn = (M << 1) | (Mw >> 31); }
+    uint32_t stop = B0 | (P & ~Pn) | (M & ~Mn);
+    if (gy == y && (gx >> 5) == wi) stop |= 1u << (gx & 31);
+    if (lane == 0) {                                   // only the cells strictly ahead of x
+        const int bx = x & 31;
+        if (sgn > 0) stop &= (bx == 31) ? 0u : ~((2u << bx) - 1u);
+        else         stop &= (1u << bx) - 1u;
+    }
+    const unsigned long long m = __ballot(stop != 0);
+    if (m == 0) return 0;                              // ran off the grid edge
+    const int L = __ffsll((long long)m) - 1;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)stop, L);
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)B0, L);
+    const int bit = sgn > 0 ? (__ffs((int)w) - 1) : (31 - __clz((int)w));
+    if ((b0 >> bit) & 1u) return 0;                    // the first stop is a wall
+    const int nx = ((wx + sgn * L) << 5) + bit;
+    return sgn > 0 ? nx - x : x - nx;
+}
+
+// Run length of jump((x,y), N or S); 0 = none.  sgn = +1 (N) / -1 (S).
+template <bool GBM>
+__device__ __forceinline__ int wave_jump_v(const Bits<GBM>& B, int x, int y, int sgn, int gx, int gy, int lane)
+{
+    for (int k0 = 1;; k0 += DMPP_WAVE) {
+        const int k = k0 + lane, ny = y + sgn * k, nn = ny + sgn;
+        const bool b0 = B.blk(x, ny);
+        const bool forced = (B.blk(x + 1, ny) && !B.blk(x + 1, nn)) || (B.blk(x - 1, ny) && !B.blk(x - 1, nn));
+        const bool stop = b0 || forced || (x == gx && ny == gy);
+        const unsigned long long m = __ballot(stop);
+        if (m) {
+            const int L = __ffsll((long long)m) - 1;
+            if ((__ballot(b0) >> L) & 1ull) return 0;
+            return k0 + L;
+        }
+    }
+}
 
 template <bool GBM>
 __global__ void __launch_bounds__(DMPP_WAVE)
 k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict__ in, const uint8_t* __restrict__ grid,
-         uint32_t* __restrict__ buckets, uint8_t* __restrict__ parents, int32_t* __restrict__ orders,
+         uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
          int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ uint32_t win[16][kWin];           // LDS tops of the 16 level stacks
+    __shared__ uint32_t o_ent[kOpenCap];       // cell | arriving direction << 24
+    __shared__ uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
+    __shared__ uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
+    __shared__ uint32_t s_min;
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
     const int lane = threadIdx.x;
-    const int W = c.grid_w, H = c.grid_h, N = W * H, cap = c.bucket_cap;
+    const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5;
     uint32_t* bm = GBM ? gbitmaps + (size_t)scene * (N >> 5) : reinterpret_cast<uint32_t*>(smem_raw);   // N/32 words
     const SceneIn& si = in[scene];
     GridOut& go = gout[scene];
     const uint8_t* g = grid + (size_t)scene * N;
-    uint32_t* bucket = buckets + (size_t)scene * 16 * cap;
-    uint8_t* parent = parents + (size_t)scene * N;
+    uint32_t* closed = gclosed + (size_t)scene * (N >> 5);        // zeroed by the host before the launch
+    uint16_t* pin = pinfo + (size_t)scene * N;
     int32_t* order = orders ? orders + (size_t)scene * order_cap : nullptr;
     int32_t* path = paths + (size_t)scene * c.max_path;
 
-    // ---- occupancy bytes -> LDS bits: lane i of a load covers bytes [16 i, 16 i + 16) of a 1-KiB
-    //      span (fully coalesced), packs them to 16 bits and stores one ds_write_b16 ----
+    // ---- occupancy bytes -> bits: lane i of a load covers bytes [16 i, 16 i + 16) of a 1-KiB span
+    //      (fully coalesced), packs them to 16 bits and stores one 16-bit word ----
     {
         const uint4* g4 = reinterpret_cast<const uint4*>(g);
         uint16_t* bm16 = reinterpret_cast<uint16_t*>(bm);
@@ -167,150 +229,145 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             }
         }
     }
-    wave_order();
+    if (GBM) __threadfence();
+    wave_sync();
 
     const int start = cell_of(c, si.grid_origin, si.loc.globalpoint.x, si.loc.globalpoint.y);
     const int goal = cell_of(c, si.grid_origin, si.goal.x, si.goal.y);
     const int gx = goal % W, gy = goal / W;
+    const int cap = min(c.bucket_cap, kOpenCap);
     int status = -1, n_exp = 0, n_push = 0, n_rounds = 0, path_cost = 0;
-    uint64_t digest = 0;       // per-lane partial, summed at the end
+    uint64_t digest = 0;
 
     if ((bm[goal >> 5] >> (goal & 31)) & 1u) {
         status = DMPP_G_GOAL_BLOCKED;
     } else {
         if (lane == 0) bm[start >> 5] &= ~(1u << (start & 31));            // the vehicle is where it is
-        int fcur = hfun(start % W, start / W, gx, gy);
-        // Open set: level k (= f/2 mod 16) is a stack whose top (<= kWin entries) lives in LDS (win[k])
-        // and whose older entries are spilled to HBM.  The two heights of level k are kept in lane k
-        // of two VGPRs and read with v_readlane.  An entry is x | y << 12 | arriving direction << 24.
-        int cnts = 0, gcn = 0;
-        {
-            const int b0 = (fcur >> 1) & 15;
-            if (lane == 0) win[b0][0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
-            if (lane == b0) cnts = 1;
+        if (lane == 0) {
+            o_ent[0] = (uint32_t)start | (8u << 24);
+            o_f2[0] = (uint16_t)(hfun(start % W, start / W, gx, gy) >> 1);
+            o_run[0] = 0;
         }
-        n_push = 1; n_rounds = 1;
-        wave_order();
-        // lane = node * 8 + direction: 8 batch nodes x 8 directions
-        const int node = lane >> 3, my_dir = lane & 7;
-        const int ddx = (my_dir == 0 || my_dir == 1 || my_dir == 7) ? 1 : ((my_dir >= 3 && my_dir <= 5) ? -1 : 0);
-        const int ddy = (my_dir >= 1 && my_dir <= 3) ? 1 : ((my_dir >= 5) ? -1 : 0);
-        const int dcost = (my_dir & 1) ? 14 : 10;
-        const unsigned long long below_node = (1ull << (node * 8)) - 1ull;      // lanes of earlier nodes
-        // every step consumes at least one entry; there are at most 8N+1 entries
-        long long guard = 10ll * N + 64;
+        wave_sync();
+        Bits<GBM> B{ bm, W, H, WW };
+        int n_open = 1, live = 1, fmax = -1;
+        n_push = 1;
+        // lanes 0..7 = the eight directions of the node being expanded
+        const int s = lane & 7;
+        const int sdx = (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0);
+        const int sdy = (s >= 1 && s <= 3) ? 1 : ((s >= 5) ? -1 : 0);
+        long long guard = 16ll * N + 1024;                 // every iteration pops an entry; entries <= 8 per closed cell
         while (status < 0) {
             if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
-            const int b = (fcur >> 1) & 15;
-            int cb = __builtin_amdgcn_readlane(cnts, b);
-            int gb = __builtin_amdgcn_readlane(gcn, b);
-            if (cb == 0 && gb == 0) {
-                // next non-empty level: 16-bit occupancy mask rotated so that bit k = level b+k
-                const unsigned m = (unsigned)(__ballot(lane < 16 && (cnts != 0 || gcn != 0)) & 0xFFFFull);
-                if (m == 0) { status = DMPP_G_NO_PATH; break; }
-                const unsigned r = ((m >> b) | (m << (16 - b))) & 0xFFFFu;
-                fcur += 2 * (__ffs((int)r) - 1);
-                n_rounds++;
-                continue;
+            if (live == 0) { status = DMPP_G_NO_PATH; break; }
+            // ---- pop: smallest f, ties to the latest push ----
+            uint32_t key = 0xFFFFFFFFu;
+            for (int i = lane; i < n_open; i += DMPP_WAVE) {
+                const uint32_t f2 = o_f2[i];
+                if (f2 != 0xFFFFu) { const uint32_t k = (f2 << 16) | (uint32_t)(0xFFFF - i); if (k < key) key = k; }
             }
-            if (cb < 8 && gb > 0) {
-                // slide the (< 8) window entries up and pull a chunk of the spilled part in underneath
-                const int take = min(kSpill, gb);
-                uint32_t v = 0;
-                if (lane < cb) v = win[b][lane];
-                wave_order();
-                if (lane < cb) win[b][lane + take] = v;
-                if (lane < take) win[b][lane] = bucket[(size_t)b * cap + (gb - take) + lane];
-                cb += take; gb -= take;
-                if (lane == b) gcn = gb;
-                wave_order();
-            }
-            // ---- pop phase: the top min(8, height) entries, node q = q-th from the top ----
-            const int avail = min(cb, 8);
-            const bool have = node < avail;
-            uint32_t e = 0;
-            if (have) e = win[b][cb - 1 - node];
-            const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu), pd = (int)(e >> 24);
-            const int cell = y * W + x;
-            bool valid = have && !((bm[cell >> 5] >> (cell & 31)) & 1u);
-            {   // a cell that appears twice among the 8: the one nearer the top wins
-                const unsigned long long om = __ballot(valid);
-                bool dup = false;
-#pragma unroll
-                for (int q = 0; q < 7; q++) {
-                    const int cq = __builtin_amdgcn_readlane(cell, q * 8);
-                    if (q < node && ((om >> (q * 8)) & 1ull) && cq == cell) dup = true;
-                }
-                if (dup) valid = false;
-            }
-            // the goal, or the node that reaches the expansion limit, ends the search at once:
-            // entries below it are not looked at
-            unsigned long long vm = __ballot(valid && my_dir == 0);                 // bit 8q = node q joins the batch
-            {
-                const int nvb = __popcll(vm & below_node);
-                const unsigned long long stop = __ballot(valid && my_dir == 0 && (cell == goal || n_exp + nvb + 1 >= c.max_expansions));
-                if (stop) {
-                    const int last = (__ffsll((long long)stop) - 1) >> 3;
-                    if (node > last) valid = false;
-                    vm = __ballot(valid && my_dir == 0);
-                }
-            }
-            // ---- close: bitmap, parent, order, digest (one lane per batch node) ----
-            if (valid && my_dir == 0) {
-                const int seq = n_exp + __popcll(vm & below_node);
-                atomicOr(&bm[cell >> 5], 1u << (cell & 31));
-                parent[cell] = (uint8_t)pd;
-                if (order && seq < order_cap) order[seq] = cell;
-                digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell);
-            }
-            n_exp += __popcll(vm);
-            if (lane == b) cnts = cb - avail;
+            if (lane == 0) s_min = 0xFFFFFFFFu;
             wave_order();
-            if (__ballot(valid && cell == goal)) { status = DMPP_G_FOUND; path_cost = fcur; break; }
+            atomicMin(&s_min, key);
+            wave_order();
+            key = s_min;
+            const int bi = 0xFFFF - (int)(key & 0xFFFFu), f = (int)(key >> 16) << 1;
+            const uint32_t e = o_ent[bi];
+            const int run_in = o_run[bi];
+            wave_order();
+            if (lane == 0) o_f2[bi] = 0xFFFFu;
+            live--;
+            if (bi == n_open - 1) n_open--;
+            const int cell = (int)(e & 0xFFFFFFu), d = (int)(e >> 24);
+            // ---- closed? (one returning atomic on the HBM bit set) ----
+            uint32_t old = 0;
+            if (lane == 0) old = atomicOr(&closed[cell >> 5], 1u << (cell & 31));
+            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+            if ((old >> (cell & 31)) & 1u) continue;
+            if (lane == 0) {
+                pin[cell] = (uint16_t)(d | (run_in << 4));
+                if (order && n_exp < order_cap) order[n_exp] = cell;
+                digest += mix64(((uint64_t)(uint32_t)n_exp << 32) | (uint32_t)cell);
+            }
+            if (f > fmax) { fmax = f; n_rounds++; }
+            n_exp++;
+            if (cell == goal) { status = DMPP_G_FOUND; path_cost = f; break; }
             if (n_exp >= c.max_expansions) { status = DMPP_G_LIMIT; break; }
-            // ---- expand phase: every lane tests one (node, direction) ----
-            const int nx = x + ddx, ny = y + ddy;
-            const bool inb = valid && nx >= 0 && ny >= 0 && nx < W && ny < H;
-            const int ncell = inb ? ny * W + nx : 0;
-            const bool push = inb && !((bm[ncell >> 5] >> (ncell & 31)) & 1u);
-            const int kb = (b + ((dcost + hfun(nx, ny, gx, gy) - hfun(x, y, gx, gy)) >> 1)) & 15;   // level of the successor
-            unsigned long long rem = __ballot(push);
-            n_push += __popcll(rem);
-            // ---- push per level in lane order (= batch order, then direction order) ----
-            bool overflow = false;
-            while (rem) {
-                const int q = __ffsll((long long)rem) - 1;
-                const int kk = __builtin_amdgcn_readlane(kb, q);
-                const bool mine = push && kb == kk;
-                const unsigned long long mk = __ballot(mine);
-                rem &= ~mk;
-                const int cnt = __popcll(mk);
-                int base = __builtin_amdgcn_readlane(cnts, kk);
-                int gbase = __builtin_amdgcn_readlane(gcn, kk);
-                if (base + gbase + cnt > cap) { overflow = true; break; }
-                if (base + cnt > kWin) {
-                    // spill the bottom 32 or 64 entries of the window to HBM, slide the rest down
-                    const int sp = ((base + cnt - kWin + kSpill - 1) / kSpill) * kSpill;
-                    if (lane < sp) bucket[(size_t)kk * cap + gbase + lane] = win[kk][lane];
-                    uint32_t v = 0;
-                    if (lane < base - sp) v = win[kk][sp + lane];
-                    wave_order();
-                    if (lane < base - sp) win[kk][lane] = v;
-                    base -= sp; gbase += sp;
-                    wave_order();
+            // ---- successors, direction s on lane s (s < 8) ----
+            const int x = cell % W, y = cell / W;
+            const int gcur = f - hfun(x, y, gx, gy);
+            bool want_jump = false; int run = 0;
+            if (lane < 8) {
+                const int tx = x + sdx, ty = y + sdy;
+                if (d == 8) {
+                    if ((s & 1) == 0) want_jump = true;
+                    else if (!B.blk(tx, ty)) run = 1;
+                } else if ((d & 1) == 0) {
+                    if (s == d) want_jump = true;
+                    else if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) {
+                        const int ddx = (d == 0) ? 1 : ((d == 4) ? -1 : 0), ddy = (d == 2) ? 1 : ((d == 6) ? -1 : 0);
+                        if (B.blk(x + sdx - ddx, y + sdy - ddy) && !B.blk(tx, ty)) run = 1;
+                    }
+                } else {
+                    const int ddx = (d == 1 || d == 7) ? 1 : -1, ddy = (d == 1 || d == 3) ? 1 : -1;
+                    if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) want_jump = true;
+                    else if (s == d) { if (!B.blk(tx, ty)) run = 1; }
+                    else if (s == ((d + 2) & 7) || s == ((d + 6) & 7)) {
+                        if (B.blk(x + (sdx - ddx) / 2, y + (sdy - ddy) / 2) && !B.blk(tx, ty)) run = 1;
+                    }
                 }
-                if (mine) {
-                    const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                    win[kk][base + r] = (uint32_t)nx | ((uint32_t)ny << 12) | ((uint32_t)my_dir << 24);
-                }
-                if (lane == kk) { cnts = base + cnt; gcn = gbase; }
             }
-            wave_order();
-            if (overflow) { status = DMPP_G_OVERFLOW; break; }
+            unsigned jm = (unsigned)__ballot(want_jump) & 0xFFu;
+            while (jm) {
+                const int js = __ffs((int)jm) - 1;
+                jm &= jm - 1;
+                int r;
+                if (js == 0) r = wave_jump_h(B, x, y, 1, gx, gy, lane);
+                else if (js == 4) r = wave_jump_h(B, x, y, -1, gx, gy, lane);
+                else if (js == 2) r = wave_jump_v(B, x, y, 1, gx, gy, lane);
+                else r = wave_jump_v(B, x, y, -1, gx, gy, lane);
+                if (lane == js) run = r;
+            }
+            // ---- push in direction order ----
+            const bool push = lane < 8 && run > 0;
+            const unsigned pm = (unsigned)__ballot(push) & 0xFFu;
+            const int cnt = __popc(pm);
+            if (cnt) {
+                if (live + cnt > cap) { status = DMPP_G_OVERFLOW; break; }
+                if (n_open + cnt > kOpenCap) {
+                    // squeeze the dead slots out, keeping the push order (ballot + prefix popcount)
+                    int w = 0;
+                    for (int i0 = 0; i0 < n_open; i0 += DMPP_WAVE) {
+                        const int i = i0 + lane;
+                        uint32_t f2 = 0xFFFFu, ee = 0; uint16_t rr = 0;
+                        if (i < n_open) { f2 = o_f2[i]; ee = o_ent[i]; rr = o_run[i]; }
+                        const bool alive = f2 != 0xFFFFu;
+                        const unsigned long long am = __ballot(alive);
+                        wave_order();
+                        if (alive) {
+                            const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+                            o_f2[w + r] = (uint16_t)f2; o_ent[w + r] = ee; o_run[w + r] = rr;
+                        }
+                        w += __popcll(am);
+                        wave_order();
+                    }
+                    n_open = w;
+                }
+                if (push) {
+                    const int nx = x + run * sdx, ny = y + run * sdy;
+                    const int fn = gcur + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
+                    const int slot = n_open + __popc(pm & ((1u << lane) - 1u));
+                    o_f2[slot] = (uint16_t)(fn >> 1);
+                    o_ent[slot] = (uint32_t)(ny * W + nx) | ((uint32_t)s << 24);
+                    o_run[slot] = (uint16_t)run;
+                }
+                n_open += cnt; live += cnt; n_push += cnt;
+                wave_order();
+            }
         }
     }
 
-    // ---- reduce the digest, walk the path back, publish ----
+    // ---- reduce the digest, rebuild the path from the runs, publish ----
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) {
         uint32_t lo = (uint32_t)digest, hi = (uint32_t)(digest >> 32);
@@ -319,30 +376,56 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     }
     int path_len = 0;
     if (status == DMPP_G_FOUND) {
-        // parent[] was written by lanes of this wave through global memory; order those stores
-        // before lane 0's loads (same CU: workgroup scope is enough)
-        wave_sync();
-        int32_t* rev = reinterpret_cast<int32_t*>(bucket);     // open set is dead now: reuse as scratch (16*cap >= max_path)
-        int L = 1;
-        if (lane == 0) {
-            int cur = goal;
-            rev[0] = cur;
-            while (cur != start && L <= N) {
-                const int pd = parent[cur] & 7;
+        // Walk the runs back from the goal (lane 0 follows dir/run of each closed cell; it wrote them
+        // itself), a chunk of runs at a time through the LDS arrays of the dead open list; all lanes
+        // write the cells of a chunk goal-first into path[], which is reversed in place at the end.
+        int cur = goal, k = 0;                            // k = cells written so far (goal side)
+        bool done = false, broken = false;
+        while (!done && !broken) {
+            int hops = 0;
+            if (lane == 0) {
+                int kk = k;
+                while (cur != start && hops < kOpenCap) {
+                    const int v = pin[cur];
+                    const int pd = v & 15, rn = v >> 4;
+                    if (rn == 0 || pd > 7 || kk > N) { broken = true; break; }
+                    const int dx = (pd == 0 || pd == 1 || pd == 7) ? 1 : ((pd >= 3 && pd <= 5) ? -1 : 0);
+                    const int dy = (pd >= 1 && pd <= 3) ? 1 : ((pd >= 5) ? -1 : 0);
+                    o_ent[hops] = (uint32_t)cur; o_run[hops] = (uint16_t)rn; o_f2[hops] = (uint16_t)pd;
+                    hops++; kk += rn;
+                    cur -= rn * (dy * W + dx);
+                }
+                done = cur == start;
+            }
+            hops = __builtin_amdgcn_readfirstlane(hops);
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            done = __builtin_amdgcn_readfirstlane((int)done) != 0;
+            broken = __builtin_amdgcn_readfirstlane((int)broken) != 0;
+            wave_sync();
+            for (int j = 0; j < hops; j++) {
+                const int ec = (int)o_ent[j], rn = o_run[j], pd = o_f2[j];
                 const int dx = (pd == 0 || pd == 1 || pd == 7) ? 1 : ((pd >= 3 && pd <= 5) ? -1 : 0);
                 const int dy = (pd >= 1 && pd <= 3) ? 1 : ((pd >= 5) ? -1 : 0);
-                cur -= dy * W + dx;
-                if (L < c.max_path) rev[L] = cur;
-                L++;
+                const int step = dy * W + dx;
+                for (int r = lane; r < rn; r += DMPP_WAVE)
+                    if (k + r < c.max_path) path[k + r] = ec - r * step;
+                k += rn;
+            }
+            wave_sync();
+        }
+        if (broken) { status = DMPP_G_INTERNAL; }
+        else {
+            if (lane == 0 && k < c.max_path) path[k] = start;
+            const int L = k + 1;
+            int keep = L;
+            if (L > c.max_path) { keep = c.max_path; status = DMPP_G_PATH_TRUNC; }
+            path_len = keep;
+            wave_sync();
+            for (int i = lane; i < keep / 2; i += DMPP_WAVE) {     // goal-first -> start-first
+                const int a0 = path[i], b0 = path[keep - 1 - i];
+                path[i] = b0; path[keep - 1 - i] = a0;
             }
         }
-        L = __shfl(L, 0, 64);
-        if (L > N) { status = DMPP_G_INTERNAL; L = 1; }
-        int keep = L;
-        if (status == DMPP_G_FOUND && L > c.max_path) { keep = c.max_path; status = DMPP_G_PATH_TRUNC; }
-        path_len = keep;
-        wave_sync();
-        for (int k = lane; k < keep; k += DMPP_WAVE) path[keep - 1 - k] = rev[k];
     }
     if (lane == 0) {
         go.order_digest = digest; go.status = status; go.n_expanded = n_exp; go.n_pushed = n_push; go.n_rounds = n_rounds;

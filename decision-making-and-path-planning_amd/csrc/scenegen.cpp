@@ -45,7 +45,7 @@ extern "C" void pp_default_config(PlannerConfig* c, int grid_w, int grid_h)
     c->grid_stage = 1;
     c->grid_w = grid_w; c->grid_h = grid_h;
     c->max_expansions = grid_w * grid_h;      // never binds unless lowered
-    c->bucket_cap = 131072;                   // entries per f level (16 levels, 8 MiB of HBM per scene)
+    c->bucket_cap = DMPP_OPEN_CAP;            // live open-list entries (the LDS-resident maximum)
     c->max_path = 4 * (grid_w > grid_h ? grid_w : grid_h);
     c->n_lattice = 16; c->lookahead_cells = 120;
     c->dynamic_obstacles = 0; c->force_replan = 0;

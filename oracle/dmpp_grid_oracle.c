@@ -77,25 +77,30 @@ void orc_rasterise(const PlannerConfig* c, GlobalPoint2D origin, const ObPoint* 
 }
 
 /* ------------------------------------------------------------------------------ */
-/* G2: bucketed A* with LIFO levels, expanded in batches of 8 (Dial's buckets over f = g + h,
- * depth-first tie-breaking, batch-synchronous so that 8 nodes x 8 directions fill a 64-lane wave).
- *   moves   : 8-connected, direction d = 0..7 = E,NE,N,NW,W,SW,S,SE, cost 10 (even d) / 14 (odd d);
- *             a move is legal iff the target cell is inside the grid, not occupied, not closed.
- *   h       : octile, 10*max(|dx|,|dy|) + 4*min(|dx|,|dy|)  (consistent, so f never decreases
- *             and a successor's f is within [f, f+28]; all f are even -> ring of 16 levels).
- *   open set: one STACK per f level.  Entries are (cell, arriving direction).  A cell may be
- *             stacked several times.
- *   step    : take the top min(8, height) entries of the stack of the lowest non-empty f, from the
- *             top down; each one whose cell is not closed is closed (expansion k = the k-th cell
- *             closed) and joins the batch; the others are dropped.  Then every batch node, in the
- *             order it was closed, pushes its legal successors in direction order 0..7 (legality
- *             is tested after the whole batch has been closed).
- *   stop    : goal closed (FOUND, at once: later entries of the step are not looked at) | open set
- *             empty (NO_PATH) | n_expanded == max_expansions (LIMIT, at once) | a stack would hold
- *             more than bucket_cap entries (OVERFLOW).
- *   path    : follow the arriving directions back from the goal.
+/* G2: jump-point A* ("stepwise JPS": straight runs are jumped, diagonal moves are single steps that
+ * go through the open list).  Optimal on the 8-connected grid with costs 10 / 14 and corner cutting
+ * allowed; it expands only jump points and diagonal steps instead of every cell of the A* ellipse.
+ *   grid    : blocked(x,y) = outside the grid or occupied; the start cell is always free.
+ *   dirs    : d = 0..7 = E,NE,N,NW,W,SW,S,SE (even = straight, cost 10 per cell; odd = diagonal, 14).
+ *   h       : octile, 10*max(|dx|,|dy|) + 4*min(|dx|,|dy|).
+ *   jump(p,s), s straight: walk p+s, p+2s, ...; at each cell c: blocked -> none; c = goal -> c;
+ *             c has a forced neighbour for travel s -> c, where forced means: a cell beside c
+ *             (perpendicular to s) is blocked and the cell beside c+s on the same side is free.
+ *   successors of a node p closed with arriving direction d (8 = start), evaluated for s = 0..7 in turn:
+ *             start      : s even -> jump(p,s);  s odd -> the cell p+s if free (one step);
+ *             d straight : s = d -> jump(p,s);  s = d+-1 (the two diagonals next to d) -> the cell p+s,
+ *                          only if forced: the cell beside p on that side is blocked and p+s is free;
+ *             d diagonal : s = d+-1 (its two straight components) -> jump(p,s);  s = d -> p+s if free;
+ *                          s = d+-2 -> p+s only if forced: the cell p + (s-d)/2 is blocked and p+s free.
+ *   open set: a list in push order; an entry is (f, cell, arriving direction, run length).  Pop the
+ *             smallest f, ties to the most recently pushed; an entry whose cell is already closed is
+ *             dropped.  The k-th cell closed is expansion k.  g is recovered as f - h(cell).
+ *   stop    : goal closed (FOUND) | open set empty (NO_PATH) | n_expanded == max_expansions (LIMIT)
+ *             | more than open_cap = min(bucket_cap, DMPP_OPEN_CAP) live entries (OVERFLOW).
+ *   path    : from the goal, each closed cell knows its arriving direction and run length; the cells
+ *             of every run are written out, start..goal.
+ *   n_rounds: number of pops whose f exceeds every f popped before (+1 for the first).
  */
-#define ORC_BATCH 8
 static const int DX[8] = { 1, 1, 0, -1, -1, -1, 0, 1 };
 static const int DY[8] = { 0, 1, 1, 1, 0, -1, -1, -1 };
 
@@ -114,88 +119,119 @@ static int hfun(int x, int y, int gx, int gy)
     return 10 * mx + 4 * mn;
 }
 
+typedef struct JGrid { const uint8_t* g; int W, H, start; } JGrid;
+static int jblk(const JGrid* G, int x, int y)
+{
+    if (x < 0 || y < 0 || x >= G->W || y >= G->H) return 1;
+    int c = y * G->W + x;
+    return c != G->start && G->g[c] != 0;
+}
+/* straight jump from (x,y) in direction s (even); returns the run length k > 0 or 0 for none */
+static int jump_straight(const JGrid* G, int x, int y, int s, int gx, int gy)
+{
+    const int dx = DX[s], dy = DY[s];
+    for (int k = 1;; k++) {
+        x += dx; y += dy;
+        if (jblk(G, x, y)) return 0;
+        if (x == gx && y == gy) return k;
+        if (dx != 0) {
+            if ((jblk(G, x, y + 1) && !jblk(G, x + dx, y + 1)) || (jblk(G, x, y - 1) && !jblk(G, x + dx, y - 1))) return k;
+        } else {
+            if ((jblk(G, x + 1, y) && !jblk(G, x + 1, y + dy)) || (jblk(G, x - 1, y) && !jblk(G, x - 1, y + dy))) return k;
+        }
+    }
+}
+
+typedef struct OEnt { int f, cell, dir, run; } OEnt;
+
 void orc_grid_search(const PlannerConfig* c, const uint8_t* grid, int start_cell, int goal_cell,
                      GridOut* out, int32_t* order, int order_cap, int32_t* path, int path_cap)
 {
-    const int W = c->grid_w, H = c->grid_h, N = W * H, cap = c->bucket_cap;
+    const int W = c->grid_w, H = c->grid_h, N = W * H;
+    const int cap = c->bucket_cap < DMPP_OPEN_CAP ? c->bucket_cap : DMPP_OPEN_CAP;
     out->start_cell = start_cell; out->goal_cell = goal_cell;
     out->status = DMPP_G_NO_PATH; out->n_expanded = 0; out->n_pushed = 0; out->n_rounds = 0;
     out->path_len = 0; out->path_cost = 0; out->order_digest = 0;
+    if (grid[goal_cell] && goal_cell != start_cell) { out->status = DMPP_G_GOAL_BLOCKED; return; }
     if (grid[goal_cell]) { out->status = DMPP_G_GOAL_BLOCKED; return; }
 
-    uint8_t* closed = (uint8_t*)malloc((size_t)N);
-    uint8_t* parent = (uint8_t*)malloc((size_t)N);
-    uint32_t* bucket = (uint32_t*)malloc(sizeof(uint32_t) * 16u * (size_t)cap);
-    int tail[16];
-    for (int i = 0; i < N; i++) closed[i] = grid[i] ? 1 : 0;
-    closed[start_cell] = 0;                       /* the vehicle is where it is */
-    memset(tail, 0, sizeof(tail));
+    JGrid G = { grid, W, H, start_cell };
+    uint8_t* closed = (uint8_t*)calloc((size_t)N, 1);
+    uint8_t* pdir = (uint8_t*)malloc((size_t)N);
+    uint16_t* prun = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)N);
+    OEnt* open = (OEnt*)malloc(sizeof(OEnt) * (size_t)(cap + 1));
+    int n_open = 0;
     const int gx = goal_cell % W, gy = goal_cell / W;
 
-    int fcur = hfun(start_cell % W, start_cell / W, gx, gy);
-    bucket[(size_t)((fcur / 2) % 16) * cap + 0] = (uint32_t)start_cell | (8u << 24);
-    tail[(fcur / 2) % 16] = 1;
-    out->n_pushed = 1; out->n_rounds = 1;
-
-    int status = -1;
+    open[n_open++] = (OEnt){ hfun(start_cell % W, start_cell / W, gx, gy), start_cell, 8, 0 };
+    out->n_pushed = 1;
+    int status = -1, fmax = -1;
     while (status < 0) {
-        int b = (fcur / 2) % 16;
-        if (tail[b] == 0) {
-            int k;
-            for (k = 1; k < 16; k++) { int bb = ((fcur / 2) + k) % 16; if (tail[bb] != 0) break; }
-            if (k == 16) { status = DMPP_G_NO_PATH; break; }
-            fcur += 2 * k; out->n_rounds++;
-            continue;
-        }
-        /* pop phase */
-        int take = tail[b] < ORC_BATCH ? tail[b] : ORC_BATCH;
-        int batch[ORC_BATCH], nb = 0;
-        for (int q = 0; q < take && status < 0; q++) {
-            uint32_t e = bucket[(size_t)b * cap + (tail[b] - 1 - q)];
-            int cell = (int)(e & 0xFFFFFFu), pd = (int)(e >> 24);
-            if (closed[cell]) continue;
-            closed[cell] = 1; parent[cell] = (uint8_t)pd;
-            int seq = out->n_expanded++;
-            if (order && seq < order_cap) order[seq] = cell;
-            out->order_digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell);
-            batch[nb++] = cell;
-            if (cell == goal_cell) { status = DMPP_G_FOUND; out->path_cost = fcur; }
-            else if (out->n_expanded >= c->max_expansions) status = DMPP_G_LIMIT;
-        }
-        tail[b] -= take;
-        if (status >= 0) break;
-        /* expand phase */
-        for (int i = 0; i < nb && status < 0; i++) {
-            int cell = batch[i];
-            int x = cell % W, y = cell / W;
-            int g = fcur - hfun(x, y, gx, gy);
-            for (int d = 0; d < 8; d++) {
-                int nx = x + DX[d], ny = y + DY[d];
-                if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
-                int n = ny * W + nx;
-                if (closed[n]) continue;
-                int fn = g + ((d & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
-                int bb = (fn / 2) % 16;
-                if (tail[bb] >= cap) { status = DMPP_G_OVERFLOW; break; }
-                bucket[(size_t)bb * cap + tail[bb]++] = (uint32_t)n | ((uint32_t)d << 24);
-                out->n_pushed++;
+        if (n_open == 0) { status = DMPP_G_NO_PATH; break; }
+        int bi = 0;
+        for (int i = 1; i < n_open; i++) if (open[i].f <= open[bi].f) bi = i;       /* smallest f, latest push */
+        OEnt e = open[bi];
+        memmove(&open[bi], &open[bi + 1], sizeof(OEnt) * (size_t)(n_open - bi - 1));  /* keeps push order */
+        n_open--;
+        if (closed[e.cell]) continue;
+        closed[e.cell] = 1; pdir[e.cell] = (uint8_t)e.dir; prun[e.cell] = (uint16_t)e.run;
+        if (e.f > fmax) { fmax = e.f; out->n_rounds++; }
+        int seq = out->n_expanded++;
+        if (order && seq < order_cap) order[seq] = e.cell;
+        out->order_digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)e.cell);
+        if (e.cell == goal_cell) { status = DMPP_G_FOUND; out->path_cost = e.f; break; }
+        if (out->n_expanded >= c->max_expansions) { status = DMPP_G_LIMIT; break; }
+        const int x = e.cell % W, y = e.cell / W, d = e.dir;
+        const int g = e.f - hfun(x, y, gx, gy);
+        for (int s = 0; s < 8 && status < 0; s++) {
+            int run = 0;                                   /* 0 = no successor in direction s */
+            const int tx = x + DX[s], ty = y + DY[s];
+            if (d == 8) {
+                if ((s & 1) == 0) run = jump_straight(&G, x, y, s, gx, gy);
+                else if (!jblk(&G, tx, ty)) run = 1;
+            } else if ((d & 1) == 0) {
+                if (s == d) run = jump_straight(&G, x, y, s, gx, gy);
+                else if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) {
+                    const int px = DX[s] - DX[d], py = DY[s] - DY[d];          /* the side the diagonal leans to */
+                    if (jblk(&G, x + px, y + py) && !jblk(&G, tx, ty)) run = 1;
+                }
+            } else {
+                if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) run = jump_straight(&G, x, y, s, gx, gy);
+                else if (s == d) { if (!jblk(&G, tx, ty)) run = 1; }
+                else if (s == ((d + 2) & 7) || s == ((d + 6) & 7)) {
+                    const int px = (DX[s] - DX[d]) / 2, py = (DY[s] - DY[d]) / 2;
+                    if (jblk(&G, x + px, y + py) && !jblk(&G, tx, ty)) run = 1;
+                }
             }
+            if (!run) continue;
+            const int nx = x + run * DX[s], ny = y + run * DY[s];
+            const int fn = g + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
+            if (n_open >= cap) { status = DMPP_G_OVERFLOW; break; }
+            open[n_open++] = (OEnt){ fn, ny * W + nx, s, run };
+            out->n_pushed++;
         }
     }
     out->status = status;
     if (status == DMPP_G_FOUND) {
         int L = 1, cur = goal_cell;
-        while (cur != start_cell) { int pd = parent[cur]; cur -= DY[pd] * W + DX[pd]; L++; }
+        while (cur != start_cell) { L += prun[cur]; cur -= prun[cur] * (DY[pdir[cur]] * W + DX[pdir[cur]]); }
         int keep = L;
-        if (L > path_cap || L > c->max_path) { keep = path_cap < c->max_path ? path_cap : c->max_path; out->status = DMPP_G_PATH_TRUNC; }
+        const int lim = path_cap < c->max_path ? path_cap : c->max_path;
+        if (L > lim) { keep = lim; out->status = DMPP_G_PATH_TRUNC; }
         out->path_len = keep;
-        cur = goal_cell;
-        for (int k = 0; k < keep; k++) {
+        /* write the last `keep` cells, goal backwards */
+        int k = 0; cur = goal_cell;
+        while (k < keep) {
             if (path) path[keep - 1 - k] = cur;
-            if (cur != start_cell) { int pd = parent[cur]; cur -= DY[pd] * W + DX[pd]; }
+            k++;
+            if (cur == start_cell) break;
+            const int step = DY[pdir[cur]] * W + DX[pdir[cur]];
+            int run = prun[cur], c2 = cur;
+            for (int r = 1; r < run && k < keep; r++) { c2 -= step; if (path) path[keep - 1 - k] = c2; k++; }
+            cur -= run * step;
         }
     }
-    free(bucket); free(parent); free(closed);
+    free(open); free(prun); free(pdir); free(closed);
 }
 
 /* ------------------------------------------------------------------------------ */

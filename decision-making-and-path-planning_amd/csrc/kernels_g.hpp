@@ -121,14 +121,36 @@ __device__ __forceinline__ uint32_t pack_nz4(uint32_t x)   // 4 bytes -> 4 bits 
 //     for the path, which is a handful of runs rather than hundreds of single cells.
 constexpr int kOpenCap = DMPP_OPEN_CAP;
 
+// minimum over the 64 lanes, returned in every lane
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#if __has_builtin(__builtin_amdgcn_wave_reduce_umin)
+    return __builtin_amdgcn_wave_reduce_umin(v, 0);
+#else
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, sft, 64); v = o < v ? o : v; }
+    return v;
+#endif
+}
+
 template <bool GBM>
 struct Bits {
     const uint32_t* bm; int W, H, WW;
     // word w of row r, all ones outside the grid
     __device__ __forceinline__ uint32_t word(int r, int w) const
     {
-        if (r < 0 || r >= H || w < 0 || w >= WW) return 0xFFFFFFFFu;
-        return bm[r * WW + w];
+        const bool ok = r >= 0 && r < H && w >= 0 && w < WW;
+        const uint32_t v = bm[ok ? r * WW + w : 0];
+        return ok ? v : 0xFFFFFFFFu;
+    }
+    // the three cells (x-1, x, x+1) of row r as bits 0..2; x is wave-uniform
+    __device__ __forceinline__ uint32_t row3(int r, int x) const
+    {
+        const int wx = x >> 5, bx = x & 31;
+        const uint32_t w = word(r, wx);
+        if (bx >= 1 && bx <= 30) return (w >> (bx - 1)) & 7u;
+        if (bx == 0) return (word(r, wx - 1) >> 31) | ((w & 3u) << 1);
+        return ((w >> 30) & 3u) | ((word(r, wx + 1) & 1u) << 2);
     }
     __device__ __forceinline__ bool blk(int x, int y) const
     {
@@ -170,9 +192,10 @@ template <bool GBM>
 __device__ __forceinline__ int wave_jump_v(const Bits<GBM>& B, int x, int y, int sgn, int gx, int gy, int lane)
 {
     for (int k0 = 1;; k0 += DMPP_WAVE) {
-        const int k = k0 + lane, ny = y + sgn * k, nn = ny + sgn;
-        const bool b0 = B.blk(x, ny);
-        const bool forced = (B.blk(x + 1, ny) && !B.blk(x + 1, nn)) || (B.blk(x - 1, ny) && !B.blk(x - 1, nn));
+        const int k = k0 + lane, ny = y + sgn * k;
+        const uint32_t a = B.row3(ny, x), nb = B.row3(ny + sgn, x);      // this row and the next one in travel direction
+        const bool b0 = (a >> 1) & 1u;
+        const bool forced = (((a >> 2) & 1u) && !((nb >> 2) & 1u)) || ((a & 1u) && !(nb & 1u));
         const bool stop = b0 || forced || (x == gx && ny == gy);
         const unsigned long long m = __ballot(stop);
         if (m) {
@@ -193,7 +216,6 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     __shared__ uint32_t o_ent[kOpenCap];       // cell | arriving direction << 24
     __shared__ uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
     __shared__ uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
-    __shared__ uint32_t s_min;
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
     const int lane = threadIdx.x;
@@ -238,6 +260,9 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     const int cap = min(c.bucket_cap, kOpenCap);
     int status = -1, n_exp = 0, n_push = 0, n_rounds = 0, path_cost = 0;
     uint64_t digest = 0;
+#ifdef DMPP_DEBUG_SEARCH
+    long long t0 = clock64(), t_pop = 0, t_closed = 0, t_jump = 0, t_push = 0, t_loaded = 0, t_done = 0; int c_iter = 0, c_jh = 0, c_jv = 0, c_scan = 0, c_compact = 0;
+#endif
 
     if ((bm[goal >> 5] >> (goal & 31)) & 1u) {
         status = DMPP_G_GOAL_BLOCKED;
@@ -257,8 +282,14 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         const int sdx = (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0);
         const int sdy = (s >= 1 && s <= 3) ? 1 : ((s >= 5) ? -1 : 0);
         long long guard = 16ll * N + 1024;                 // every iteration pops an entry; entries <= 8 per closed cell
+#ifdef DMPP_DEBUG_SEARCH
+        t_loaded = clock64();
+#endif
         while (status < 0) {
             if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
+#ifdef DMPP_DEBUG_SEARCH
+            c_iter++; long long ta = clock64(); c_scan += (n_open + 63) / 64;
+#endif
             if (live == 0) { status = DMPP_G_NO_PATH; break; }
             // ---- pop: smallest f, ties to the latest push ----
             uint32_t key = 0xFFFFFFFFu;
@@ -266,11 +297,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 const uint32_t f2 = o_f2[i];
                 if (f2 != 0xFFFFu) { const uint32_t k = (f2 << 16) | (uint32_t)(0xFFFF - i); if (k < key) key = k; }
             }
-            if (lane == 0) s_min = 0xFFFFFFFFu;
-            wave_order();
-            atomicMin(&s_min, key);
-            wave_order();
-            key = s_min;
+            key = wave_min_u32(key);
             const int bi = 0xFFFF - (int)(key & 0xFFFFu), f = (int)(key >> 16) << 1;
             const uint32_t e = o_ent[bi];
             const int run_in = o_run[bi];
@@ -279,10 +306,16 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             live--;
             if (bi == n_open - 1) n_open--;
             const int cell = (int)(e & 0xFFFFFFu), d = (int)(e >> 24);
+#ifdef DMPP_DEBUG_SEARCH
+            long long tb = clock64(); t_pop += tb - ta;
+#endif
             // ---- closed? (one returning atomic on the HBM bit set) ----
             uint32_t old = 0;
             if (lane == 0) old = atomicOr(&closed[cell >> 5], 1u << (cell & 31));
             old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+#ifdef DMPP_DEBUG_SEARCH
+            long long tc = clock64(); t_closed += tc - tb;
+#endif
             if ((old >> (cell & 31)) & 1u) continue;
             if (lane == 0) {
                 pin[cell] = (uint16_t)(d | (run_in << 4));
@@ -322,12 +355,18 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 const int js = __ffs((int)jm) - 1;
                 jm &= jm - 1;
                 int r;
+#ifdef DMPP_DEBUG_SEARCH
+                if (js == 0 || js == 4) c_jh++; else c_jv++;
+#endif
                 if (js == 0) r = wave_jump_h(B, x, y, 1, gx, gy, lane);
                 else if (js == 4) r = wave_jump_h(B, x, y, -1, gx, gy, lane);
                 else if (js == 2) r = wave_jump_v(B, x, y, 1, gx, gy, lane);
                 else r = wave_jump_v(B, x, y, -1, gx, gy, lane);
                 if (lane == js) run = r;
             }
+#ifdef DMPP_DEBUG_SEARCH
+            long long td = clock64(); t_jump += td - tc;
+#endif
             // ---- push in direction order ----
             const bool push = lane < 8 && run > 0;
             const unsigned pm = (unsigned)__ballot(push) & 0xFFu;
@@ -335,6 +374,9 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             if (cnt) {
                 if (live + cnt > cap) { status = DMPP_G_OVERFLOW; break; }
                 if (n_open + cnt > kOpenCap) {
+#ifdef DMPP_DEBUG_SEARCH
+                    c_compact++;
+#endif
                     // squeeze the dead slots out, keeping the push order (ballot + prefix popcount)
                     int w = 0;
                     for (int i0 = 0; i0 < n_open; i0 += DMPP_WAVE) {
@@ -364,9 +406,15 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 n_open += cnt; live += cnt; n_push += cnt;
                 wave_order();
             }
+#ifdef DMPP_DEBUG_SEARCH
+            t_push += clock64() - td;
+#endif
         }
     }
 
+#ifdef DMPP_DEBUG_SEARCH
+    t_done = clock64();
+#endif
     // ---- reduce the digest, rebuild the path from the runs, publish ----
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) {
@@ -427,6 +475,10 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             }
         }
     }
+#ifdef DMPP_DEBUG_SEARCH
+    if (lane == 0) { long long te = clock64(); int32_t* dbg = path + c.max_path - 16; dbg[0] = c_iter; dbg[1] = c_jh; dbg[2] = c_jv; dbg[3] = c_scan; dbg[4] = c_compact;
+        dbg[5] = (int)((t_loaded - t0) >> 4); dbg[6] = (int)(t_pop >> 4); dbg[7] = (int)(t_closed >> 4); dbg[8] = (int)(t_jump >> 4); dbg[9] = (int)(t_push >> 4); dbg[10] = (int)((te - t_done) >> 4); dbg[11] = (int)((te - t0) >> 4); }
+#endif
     if (lane == 0) {
         go.order_digest = digest; go.status = status; go.n_expanded = n_exp; go.n_pushed = n_push; go.n_rounds = n_rounds;
         go.path_len = path_len; go.path_cost = path_cost; go.start_cell = start; go.goal_cell = goal;

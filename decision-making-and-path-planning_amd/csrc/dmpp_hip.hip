@@ -69,7 +69,9 @@ int check_cfg(const PlannerConfig* c)
 {
     if (!c) return fail(PP_ERR_ARG, "config is null");
     if (c->grid_stage) {
-        if (c->grid_w <= 0 || c->grid_h <= 0 || (c->grid_w % 32) != 0) return fail(PP_ERR_ARG, "grid_w must be a positive multiple of 32");
+        if (c->grid_w <= 0 || c->grid_h <= 0 || (c->grid_w % 32) != 0 || (c->grid_h % 32) != 0)
+            return fail(PP_ERR_ARG, "grid_w and grid_h must be positive multiples of 32");
+        if (c->grid_w > 2048 || c->grid_h > 2048) return fail(PP_ERR_ARG, "grids above 2048x2048 are not supported (one wave scans 64 words of a line)");
         if ((long long)c->grid_w * c->grid_h > (1ll << 24)) return fail(PP_ERR_ARG, "grid larger than 2^24 cells (cell index is 24 bits in an open-set entry)");
         if (c->bucket_cap < 16 || c->max_path < 2) return fail(PP_ERR_ARG, "bucket_cap/max_path too small");
         if (!(c->cell > 0)) return fail(PP_ERR_ARG, "cell size must be positive");
@@ -118,7 +120,7 @@ int setup_grid_launch(pp_planner* h)
     int band = 65536 / c.grid_w; if (band < 1) band = 1; if (band > c.grid_h) band = c.grid_h;
     h->raster_band_rows = band;
     // search: bitmap in LDS when it fits next to nothing else, else in HBM
-    const size_t bm_bytes = N / 8;
+    const size_t bm_bytes = 2 * (N / 8);              // row-major + column-major obstacle bits
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
     const size_t lds_max = prop.sharedMemPerBlock;        // 64 KiB default, 160 KiB opt-in on gfx950
@@ -135,7 +137,7 @@ int setup_grid_launch(pp_planner* h)
         if (e != hipSuccess) { (void)hipGetLastError(); h->search_gbm = true; h->search_lds = 0; }
     }
     if (h->search_gbm && !h->d_gbm) {
-        int r = dmalloc(&h->d_gbm, (size_t)h->caps.max_scenes * (h->grid_cells / 32));
+        int r = dmalloc(&h->d_gbm, (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
         if (r) return r;
     }
     return PP_OK;

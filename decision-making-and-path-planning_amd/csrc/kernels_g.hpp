@@ -159,50 +159,106 @@ struct Bits {
     }
 };
 
-// Run length of jump((x,y), E or W); 0 = none.  sgn = +1 (E) / -1 (W).  All 64 lanes take part.
-template <bool GBM>
-__device__ __forceinline__ int wave_jump_h(const Bits<GBM>& B, int x, int y, int sgn, int gx, int gy, int lane)
+// One straight jump as a line scan.  A "view" is a bit matrix of NL lines x LW words: the row-major
+// bitmap for E/W (line = y, position along the line = x) or the transposed one for N/S (line = x,
+// position = y); the forced-neighbour test only needs the two neighbouring lines, so both axes share
+// the code.  run = cells travelled to the first stop, 0 = none.
+struct LineJob {
+    const uint32_t* base; int LW, NL;      // view
+    int line, pos, sgn;                    // start and direction along the line
+    int gline, gpos;                       // goal in this view
+    bool active;
+};
+__device__ __forceinline__ uint32_t view_word(const LineJob& J, int line, int w)
 {
-    const int wx = x >> 5, wi = wx + sgn * lane, nwi = wi + sgn;
-    const uint32_t B0 = B.word(y, wi), P = B.word(y + 1, wi), M = B.word(y - 1, wi);
-    const uint32_t Pw = B.word(y + 1, nwi), Mw = B.word(y - 1, nwi);
+    const bool ok = line >= 0 && line < J.NL && w >= 0 && w < J.LW;
+    const uint32_t v = J.base[ok ? line * J.LW + w : 0];
+    return ok ? v : 0xFFFFFFFFu;
+}
+// stop mask of the 32-cell word `k` words ahead of the start (k = 0: only the cells strictly ahead)
+__device__ __forceinline__ uint32_t line_stop(const LineJob& J, int k, uint32_t& B0)
+{
+    const int wp = J.pos >> 5, wi = wp + J.sgn * k, nwi = wi + J.sgn;
+    B0 = view_word(J, J.line, wi);
+    const uint32_t P = view_word(J, J.line + 1, wi), M = view_word(J, J.line - 1, wi);
+    const uint32_t Pw = view_word(J, J.line + 1, nwi), Mw = view_word(J, J.line - 1, nwi);
     uint32_t Pn, Mn;
-    if (sgn > 0) { Pn = (P >> 1) | (Pw << 31); Mn = (M >> 1) | (Mw << 31); }
-    else         { Pn = (P << 1) | (Pw >> 31); Mn = (M << 1) | (Mw >> 31); }
+    if (J.sgn > 0) { Pn = (P >> 1) | (Pw << 31); Mn = (M >> 1) | (Mw << 31); }
+    else           { Pn = (P << 1) | (Pw >> 31); Mn = (M << 1) | (Mw >> 31); }
     uint32_t stop = B0 | (P & ~Pn) | (M & ~Mn);
-    if (gy == y && (gx >> 5) == wi) stop |= 1u << (gx & 31);
-    if (lane == 0) {                                   // only the cells strictly ahead of x
-        const int bx = x & 31;
-        if (sgn > 0) stop &= (bx == 31) ? 0u : ~((2u << bx) - 1u);
-        else         stop &= (1u << bx) - 1u;
+    if (J.gline == J.line && (J.gpos >> 5) == wi) stop |= 1u << (J.gpos & 31);
+    if (k == 0) {
+        const int bp = J.pos & 31;
+        if (J.sgn > 0) stop &= (bp == 31) ? 0u : ~((2u << bp) - 1u);
+        else           stop &= (1u << bp) - 1u;
     }
-    const unsigned long long m = __ballot(stop != 0);
-    if (m == 0) return 0;                              // ran off the grid edge
-    const int L = __ffsll((long long)m) - 1;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)stop, L);
-    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)B0, L);
-    const int bit = sgn > 0 ? (__ffs((int)w) - 1) : (31 - __clz((int)w));
+    return stop;
+}
+__device__ __forceinline__ int line_run(const LineJob& J, int k, uint32_t w, uint32_t b0)
+{
+    const int bit = J.sgn > 0 ? (__ffs((int)w) - 1) : (31 - __clz((int)w));
     if ((b0 >> bit) & 1u) return 0;                    // the first stop is a wall
-    const int nx = ((wx + sgn * L) << 5) + bit;
-    return sgn > 0 ? nx - x : x - nx;
+    const int np = (((J.pos >> 5) + J.sgn * k) << 5) + bit;
+    return J.sgn > 0 ? np - J.pos : J.pos - np;
+}
+// Two jumps in one pass: lanes 0..31 scan job A, lanes 32..63 job B (32 words = 1024 cells each).
+__device__ __forceinline__ void wave_jump_pair(const LineJob& A, const LineJob& Bj, int lane, int& runA, int& runB)
+{
+    const bool hi = lane >= 32;
+    LineJob J;
+    J.base = hi ? Bj.base : A.base; J.LW = hi ? Bj.LW : A.LW; J.NL = hi ? Bj.NL : A.NL;
+    J.line = hi ? Bj.line : A.line; J.pos = hi ? Bj.pos : A.pos; J.sgn = hi ? Bj.sgn : A.sgn;
+    J.gline = hi ? Bj.gline : A.gline; J.gpos = hi ? Bj.gpos : A.gpos; J.active = hi ? Bj.active : A.active;
+    uint32_t B0 = 0, stop = 0;
+    if (J.active) stop = line_stop(J, lane & 31, B0);
+    const unsigned long long m = __ballot(stop != 0);
+    runA = 0; runB = 0;
+    const unsigned mA = (unsigned)m, mB = (unsigned)(m >> 32);
+    if (mA) {
+        const int L = __ffs((int)mA) - 1;
+        runA = line_run(A, L, (uint32_t)__builtin_amdgcn_readlane((int)stop, L), (uint32_t)__builtin_amdgcn_readlane((int)B0, L));
+    }
+    if (mB) {
+        const int L = __ffs((int)mB) - 1;
+        runB = line_run(Bj, L, (uint32_t)__builtin_amdgcn_readlane((int)stop, 32 + L), (uint32_t)__builtin_amdgcn_readlane((int)B0, 32 + L));
+    }
+}
+// One jump on the whole wave (64 words = 2048 cells): for views wider than 32 words.
+__device__ __forceinline__ int wave_jump_one(const LineJob& J, int lane)
+{
+    uint32_t B0 = 0;
+    const uint32_t stop = line_stop(J, lane, B0);
+    const unsigned long long m = __ballot(stop != 0);
+    if (m == 0) return 0;
+    const int L = __ffsll((long long)m) - 1;
+    return line_run(J, L, (uint32_t)__builtin_amdgcn_readlane((int)stop, L), (uint32_t)__builtin_amdgcn_readlane((int)B0, L));
 }
 
-// Run length of jump((x,y), N or S); 0 = none.  sgn = +1 (N) / -1 (S).
-template <bool GBM>
-__device__ __forceinline__ int wave_jump_v(const Bits<GBM>& B, int x, int y, int sgn, int gx, int gy, int lane)
+// Bit-matrix transpose of the row-major bitmap (H lines x WW words) into the column-major one
+// (W lines x HW words), 32x32 blocks in registers: each lane takes blocks lane, lane+64, ...
+__device__ __forceinline__ void transpose_bits(const uint32_t* src, uint32_t* dst, int W, int H, int lane)
 {
-    for (int k0 = 1;; k0 += DMPP_WAVE) {
-        const int k = k0 + lane, ny = y + sgn * k;
-        const uint32_t a = B.row3(ny, x), nb = B.row3(ny + sgn, x);      // this row and the next one in travel direction
-        const bool b0 = (a >> 1) & 1u;
-        const bool forced = (((a >> 2) & 1u) && !((nb >> 2) & 1u)) || ((a & 1u) && !(nb & 1u));
-        const bool stop = b0 || forced || (x == gx && ny == gy);
-        const unsigned long long m = __ballot(stop);
-        if (m) {
-            const int L = __ffsll((long long)m) - 1;
-            if ((__ballot(b0) >> L) & 1ull) return 0;
-            return k0 + L;
+    const int WW = W >> 5, HW = H >> 5;
+    for (int blk = lane; blk < WW * HW; blk += DMPP_WAVE) {
+        const int bx = blk % WW, by = blk / WW;
+        uint32_t a[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) a[i] = src[(by * 32 + i) * WW + bx];
+        // a[i] bit j = cell (32 bx + j, 32 by + i)  ->  t[j] bit i
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) {
+            const uint32_t mask = sft == 16 ? 0x0000FFFFu : sft == 8 ? 0x00FF00FFu : sft == 4 ? 0x0F0F0F0Fu : sft == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                if ((i & sft) == 0) {
+                    const uint32_t lo = a[i], hi = a[i + sft];
+                    a[i] = (lo & mask) | ((hi & mask) << sft);
+                    a[i + sft] = ((lo >> sft) & mask) | (hi & ~mask);
+                }
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 32; j++) dst[(bx * 32 + j) * HW + by] = a[j];
     }
 }
 
@@ -220,7 +276,10 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     if (scene >= n_scenes) return;
     const int lane = threadIdx.x;
     const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5;
-    uint32_t* bm = GBM ? gbitmaps + (size_t)scene * (N >> 5) : reinterpret_cast<uint32_t*>(smem_raw);   // N/32 words
+    // obstacle bits twice: row-major for E/W scans, column-major for N/S scans (N/32 words each)
+    uint32_t* bm = GBM ? gbitmaps + (size_t)scene * 2 * (N >> 5) : reinterpret_cast<uint32_t*>(smem_raw);
+    uint32_t* bmT = bm + (N >> 5);
+    const int HW = H >> 5;
     const SceneIn& si = in[scene];
     GridOut& go = gout[scene];
     const uint8_t* g = grid + (size_t)scene * N;
@@ -268,13 +327,16 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         status = DMPP_G_GOAL_BLOCKED;
     } else {
         if (lane == 0) bm[start >> 5] &= ~(1u << (start & 31));            // the vehicle is where it is
+        wave_sync();
+        transpose_bits(bm, bmT, W, H, lane);
+        if (GBM) __threadfence();
         if (lane == 0) {
             o_ent[0] = (uint32_t)start | (8u << 24);
             o_f2[0] = (uint16_t)(hfun(start % W, start / W, gx, gy) >> 1);
             o_run[0] = 0;
         }
         wave_sync();
-        Bits<GBM> B{ bm, W, H, WW };
+        Bits<GBM> B{ bm, W, H, WW };     // single-cell tests of the diagonal steps
         int n_open = 1, live = 1, fmax = -1;
         n_push = 1;
         // lanes 0..7 = the eight directions of the node being expanded
@@ -352,21 +414,30 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             }
             unsigned jm = (unsigned)__ballot(want_jump) & 0xFFu;
             while (jm) {
-                const int js = __ffs((int)jm) - 1;
-                jm &= jm - 1;
-                int r;
-#ifdef DMPP_DEBUG_SEARCH
-                if (js == 0 || js == 4) c_jh++; else c_jv++;
-#endif
-                if (js == 0) r = wave_jump_h(B, x, y, 1, gx, gy, lane);
-                else if (js == 4) r = wave_jump_h(B, x, y, -1, gx, gy, lane);
-                else if (js == 2) r = wave_jump_v(B, x, y, 1, gx, gy, lane);
-                else r = wave_jump_v(B, x, y, -1, gx, gy, lane);
-                if (lane == js) run = r;
+                // up to two of the wanted jumps per pass (E/W on the row view, N/S on the column view)
+                const int ja = __ffs((int)jm) - 1; jm &= jm - 1;
+                int jb = -1;
+                if (jm && WW <= 32 && HW <= 32) { jb = __ffs((int)jm) - 1; jm &= jm - 1; }
+                LineJob A, Bj;
+                {
+                    const bool horiz = ja == 0 || ja == 4;
+                    A.base = horiz ? bm : bmT; A.LW = horiz ? WW : HW; A.NL = horiz ? H : W;
+                    A.line = horiz ? y : x; A.pos = horiz ? x : y; A.sgn = (ja == 0 || ja == 2) ? 1 : -1;
+                    A.gline = horiz ? gy : gx; A.gpos = horiz ? gx : gy; A.active = true;
+                }
+                {
+                    const int jj = jb < 0 ? 0 : jb;
+                    const bool horiz = jj == 0 || jj == 4;
+                    Bj.base = horiz ? bm : bmT; Bj.LW = horiz ? WW : HW; Bj.NL = horiz ? H : W;
+                    Bj.line = horiz ? y : x; Bj.pos = horiz ? x : y; Bj.sgn = (jj == 0 || jj == 2) ? 1 : -1;
+                    Bj.gline = horiz ? gy : gx; Bj.gpos = horiz ? gx : gy; Bj.active = jb >= 0;
+                }
+                int ra = 0, rb = 0;
+                if (WW <= 32 && HW <= 32) wave_jump_pair(A, Bj, lane, ra, rb);
+                else ra = wave_jump_one(A, lane);
+                if (lane == ja) run = ra;
+                if (jb >= 0 && lane == jb) run = rb;
             }
-#ifdef DMPP_DEBUG_SEARCH
-            long long td = clock64(); t_jump += td - tc;
-#endif
             // ---- push in direction order ----
             const bool push = lane < 8 && run > 0;
             const unsigned pm = (unsigned)__ballot(push) & 0xFFu;

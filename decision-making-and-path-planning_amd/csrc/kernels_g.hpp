@@ -269,7 +269,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
          int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ uint32_t o_ent[kOpenCap];       // cell | arriving direction << 24
+    __shared__ uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24
     __shared__ uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
     __shared__ uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
     const int scene = blockIdx.x;
@@ -331,7 +331,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         transpose_bits(bm, bmT, W, H, lane);
         if (GBM) __threadfence();
         if (lane == 0) {
-            o_ent[0] = (uint32_t)start | (8u << 24);
+            o_ent[0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
             o_f2[0] = (uint16_t)(hfun(start % W, start / W, gx, gy) >> 1);
             o_run[0] = 0;
         }
@@ -367,7 +367,8 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             if (lane == 0) o_f2[bi] = 0xFFFFu;
             live--;
             if (bi == n_open - 1) n_open--;
-            const int cell = (int)(e & 0xFFFFFFu), d = (int)(e >> 24);
+            const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu), d = (int)(e >> 24);
+            const int cell = y * W + x;
 #ifdef DMPP_DEBUG_SEARCH
             long long tb = clock64(); t_pop += tb - ta;
 #endif
@@ -388,29 +389,23 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             n_exp++;
             if (cell == goal) { status = DMPP_G_FOUND; path_cost = f; break; }
             if (n_exp >= c.max_expansions) { status = DMPP_G_LIMIT; break; }
-            // ---- successors, direction s on lane s (s < 8) ----
-            const int x = cell % W, y = cell / W;
+            // ---- successors, direction s on lane s (s < 8): branch-free form of the rule table ----
             const int gcur = f - hfun(x, y, gx, gy);
             bool want_jump = false; int run = 0;
-            if (lane < 8) {
-                const int tx = x + sdx, ty = y + sdy;
-                if (d == 8) {
-                    if ((s & 1) == 0) want_jump = true;
-                    else if (!B.blk(tx, ty)) run = 1;
-                } else if ((d & 1) == 0) {
-                    if (s == d) want_jump = true;
-                    else if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) {
-                        const int ddx = (d == 0) ? 1 : ((d == 4) ? -1 : 0), ddy = (d == 2) ? 1 : ((d == 6) ? -1 : 0);
-                        if (B.blk(x + sdx - ddx, y + sdy - ddy) && !B.blk(tx, ty)) run = 1;
-                    }
-                } else {
-                    const int ddx = (d == 1 || d == 7) ? 1 : -1, ddy = (d == 1 || d == 3) ? 1 : -1;
-                    if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) want_jump = true;
-                    else if (s == d) { if (!B.blk(tx, ty)) run = 1; }
-                    else if (s == ((d + 2) & 7) || s == ((d + 6) & 7)) {
-                        if (B.blk(x + (sdx - ddx) / 2, y + (sdy - ddy) / 2) && !B.blk(tx, ty)) run = 1;
-                    }
-                }
+            {
+                const int dd = d & 7;
+                const int ddx = (dd == 0 || dd == 1 || dd == 7) ? 1 : ((dd >= 3 && dd <= 5) ? -1 : 0);
+                const int ddy = (dd >= 1 && dd <= 3) ? 1 : ((dd >= 5) ? -1 : 0);
+                const int rel = (s - d) & 7;
+                const bool is_start = d == 8, d_odd = (d & 1) != 0 && !is_start, d_even = !d_odd && !is_start;
+                want_jump = lane < 8 && ((is_start && (s & 1) == 0) || (d_even && rel == 0) || (d_odd && (rel == 1 || rel == 7)));
+                const bool plain = lane < 8 && ((is_start && (s & 1) != 0) || (d_odd && rel == 0));
+                const bool sided = lane < 8 && ((d_even && (rel == 1 || rel == 7)) || (d_odd && (rel == 2 || rel == 6)));
+                // the cell beside p on the side direction s leans to: (s - d) for a straight d, (s - d)/2 for a diagonal d
+                const int px = d_odd ? (sdx - ddx) / 2 : sdx - ddx, py = d_odd ? (sdy - ddy) / 2 : sdy - ddy;
+                const bool t_free = (plain || sided) && !B.blk(x + sdx, y + sdy);
+                const bool side_blk = sided && B.blk(x + px, y + py);
+                if ((plain && t_free) || (sided && side_blk && t_free)) run = 1;
             }
             unsigned jm = (unsigned)__ballot(want_jump) & 0xFFu;
             while (jm) {
@@ -438,6 +433,9 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 if (lane == ja) run = ra;
                 if (jb >= 0 && lane == jb) run = rb;
             }
+#ifdef DMPP_DEBUG_SEARCH
+            long long td = clock64(); t_jump += td - tc;
+#endif
             // ---- push in direction order ----
             const bool push = lane < 8 && run > 0;
             const unsigned pm = (unsigned)__ballot(push) & 0xFFu;
@@ -471,7 +469,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                     const int fn = gcur + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
                     const int slot = n_open + __popc(pm & ((1u << lane) - 1u));
                     o_f2[slot] = (uint16_t)(fn >> 1);
-                    o_ent[slot] = (uint32_t)(ny * W + nx) | ((uint32_t)s << 24);
+                    o_ent[slot] = (uint32_t)nx | ((uint32_t)ny << 12) | ((uint32_t)s << 24);
                     o_run[slot] = (uint16_t)run;
                 }
                 n_open += cnt; live += cnt; n_push += cnt;

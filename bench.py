@@ -175,6 +175,16 @@ def main():
         dom_ms, dom_launches = kms[dom]
         avg_ms = dom_ms / max(dom_launches, 1)
         achieved = per_kernel[dom] * n / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/profile.sh:
+        # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload; FETCH_SIZE doubled per the
+        # gfx950 note of MI355X_MICROARCH.md).  Only quoted for the workload it was measured on.
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r1_pmc.json")
+        if os.path.exists(pmc_path) and n == 1024 and args.grid == 512 and n_obs == 64 and not args.dynamic:
+            pmc = json.load(open(pmc_path))["kernels"]
+            for name, k in pmc.items():
+                if name.split("<")[0] == dom and "hbm_bytes_gfx950_corrected" in k:
+                    traffic, traffic_src = k["hbm_bytes_gfx950_corrected"], "profiles/r1_pmc.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
         line = {
             "metric": "planning ticks/sec (batched scenes), %dx%d grid" % (args.grid, args.grid),
             "value": n * world * args.steps / dt,
@@ -199,7 +209,7 @@ def main():
             "search_status_counts": np.bincount(gout["status"], minlength=6).tolist(),
             "kernel_ms_avg": {k: (v[0] / max(v[1], 1)) for k, v in kms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": per_kernel[dom] * n, "avg_launch_ms": avg_ms},
             "cpu_baseline": cpu,
         }

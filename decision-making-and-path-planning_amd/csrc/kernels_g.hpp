@@ -58,27 +58,46 @@ k_rasterise(PlannerConfig c, int n_scenes, int band_rows, const SceneIn* __restr
     const double ox = si.grid_origin.x, oy = si.grid_origin.y;
     const int m = si.obs_n;
     const ObPoint* obs = obs_now + si.obs_off;
-    // every thread walks the obstacle list; the cells of one footprint's bounding box (clipped
-    // to this band) are spread over the 256 threads
-    for (int j = 0; j < m; j++) {
-        const ObPoint o = obs[j];
-        const double R = (double)o.radius + c.inflate;
-        int ix0 = (int)floor((o.x - R - ox) / c.cell) - 1, ix1 = (int)floor((o.x + R - ox) / c.cell) + 1;
-        int iy0 = (int)floor((o.y - R - oy) / c.cell) - 1, iy1 = (int)floor((o.y + R - oy) / c.cell) + 1;
-        ix0 = max(ix0, 0); ix1 = min(ix1, W - 1);
-        iy0 = max(iy0, row0); iy1 = min(iy1, row0 + rows - 1);
-        const int bw = ix1 - ix0 + 1, bh = iy1 - iy0 + 1;
-        if (bw <= 0 || bh <= 0) continue;
-        const double R2 = R * R;
-        for (int t = tid; t < bw * bh; t += kRasterBlock) {
-            const int iy = iy0 + t / bw, ix = ix0 + t % bw;
-            const double cx = ox + ((double)ix + 0.5) * c.cell, cy = oy + ((double)iy + 0.5) * c.cell;
-            const double dx = cx - o.x, dy = cy - o.y;
-            if (dx * dx + dy * dy <= R2) {
-                const int b = (iy - row0) * W + ix;
-                atomicOr(&bits[b >> 5], 1u << (b & 31));
+    // Footprints that touch this band: one thread per obstacle computes the clipped bounding box once,
+    // the hits are compacted into an LDS list (chunks of 256 obstacles); then, per listed footprint, the
+    // cells of its box are spread over the 256 threads.
+    __shared__ int s_box[kRasterBlock][4];
+    __shared__ double s_par[kRasterBlock][3];      // x, y, R^2
+    __shared__ int s_cnt;
+    for (int j0 = 0; j0 < m; j0 += kRasterBlock) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        const int j = j0 + tid;
+        if (j < m) {
+            const ObPoint o = obs[j];
+            const double R = (double)o.radius + c.inflate;
+            int ix0 = (int)floor((o.x - R - ox) / c.cell) - 1, ix1 = (int)floor((o.x + R - ox) / c.cell) + 1;
+            int iy0 = (int)floor((o.y - R - oy) / c.cell) - 1, iy1 = (int)floor((o.y + R - oy) / c.cell) + 1;
+            ix0 = max(ix0, 0); ix1 = min(ix1, W - 1);
+            iy0 = max(iy0, row0); iy1 = min(iy1, row0 + rows - 1);
+            if (ix1 >= ix0 && iy1 >= iy0) {
+                const int k = atomicAdd(&s_cnt, 1);        // order does not matter: the bits are OR-ed
+                s_box[k][0] = ix0; s_box[k][1] = ix1; s_box[k][2] = iy0; s_box[k][3] = iy1;
+                s_par[k][0] = o.x; s_par[k][1] = o.y; s_par[k][2] = R * R;
             }
         }
+        __syncthreads();
+        const int nhit = s_cnt;
+        for (int k = 0; k < nhit; k++) {
+            const int ix0 = s_box[k][0], iy0 = s_box[k][2];
+            const int bw = s_box[k][1] - ix0 + 1, bh = s_box[k][3] - iy0 + 1;
+            const double cxo = s_par[k][0], cyo = s_par[k][1], R2 = s_par[k][2];
+            for (int t = tid; t < bw * bh; t += kRasterBlock) {
+                const int iy = iy0 + t / bw, ix = ix0 + t % bw;
+                const double cx = ox + ((double)ix + 0.5) * c.cell, cy = oy + ((double)iy + 0.5) * c.cell;
+                const double dx = cx - cxo, dy = cy - cyo;
+                if (dx * dx + dy * dy <= R2) {
+                    const int b = (iy - row0) * W + ix;
+                    atomicOr(&bits[b >> 5], 1u << (b & 31));
+                }
+            }
+        }
+        __syncthreads();
     }
     __syncthreads();
     // expand 16 bits -> 16 bytes per lane per store (uint4), fully coalesced
@@ -120,17 +139,19 @@ __device__ __forceinline__ uint32_t pack_nz4(uint32_t x)   // 4 bytes -> 4 bits 
 //   * closed cells are a bit set in HBM (one returning atomicOr per pop) plus dir/run per closed cell
 //     for the path, which is a handful of runs rather than hundreds of single cells.
 constexpr int kOpenCap = DMPP_OPEN_CAP;
+constexpr int kClosedTab = 2048, kClosedMax = 1536;     // LDS closed-set hash; beyond kClosedMax the HBM bit set answers
 
-// minimum over the 64 lanes, returned in every lane
+// minimum over the 64 lanes, returned in every lane: DPP prefix-min inside each row of 16 lanes
+// (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row results to lane 63.
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-#if __has_builtin(__builtin_amdgcn_wave_reduce_umin)
-    return __builtin_amdgcn_wave_reduce_umin(v, 0);
-#else
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, sft, 64); v = o < v ? o : v; }
-    return v;
-#endif
+#define DMPP_DPP_MIN(ctrl, rowmask)                                                                              \
+    { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, ctrl, rowmask, 0xf, false); \
+      v = t < v ? t : v; }
+    DMPP_DPP_MIN(0x111, 0xf) DMPP_DPP_MIN(0x112, 0xf) DMPP_DPP_MIN(0x114, 0xf) DMPP_DPP_MIN(0x118, 0xf)
+    DMPP_DPP_MIN(0x142, 0xa) DMPP_DPP_MIN(0x143, 0xc)
+#undef DMPP_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 template <bool GBM>
@@ -272,6 +293,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     __shared__ uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24
     __shared__ uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
     __shared__ uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
+    __shared__ uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
     const int lane = threadIdx.x;
@@ -330,6 +352,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         wave_sync();
         transpose_bits(bm, bmT, W, H, lane);
         if (GBM) __threadfence();
+        for (int i = lane; i < kClosedTab; i += DMPP_WAVE) c_tab[i] = 0;
         if (lane == 0) {
             o_ent[0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
             o_f2[0] = (uint16_t)(hfun(start % W, start / W, gx, gy) >> 1);
@@ -372,14 +395,31 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
 #ifdef DMPP_DEBUG_SEARCH
             long long tb = clock64(); t_pop += tb - ta;
 #endif
-            // ---- closed? (one returning atomic on the HBM bit set) ----
-            uint32_t old = 0;
-            if (lane == 0) old = atomicOr(&closed[cell >> 5], 1u << (cell & 31));
-            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+            // ---- closed?  The HBM bit set always gets the bit (fire and forget); the answer comes from
+            //      the LDS hash while it has room, from the returning HBM atomic afterwards ----
+            bool was_closed;
+            if (n_exp < kClosedMax) {
+                if (lane == 0) atomicOr(&closed[cell >> 5], 1u << (cell & 31));
+                const uint32_t keyc = (uint32_t)cell + 1u;
+                uint32_t hh = ((uint32_t)cell * 2654435761u) >> 21;
+                was_closed = false;
+                for (int probe = 0; probe < kClosedTab; probe++) {
+                    const uint32_t v = c_tab[hh];
+                    if (v == keyc) { was_closed = true; break; }
+                    if (v == 0) { if (lane == 0) c_tab[hh] = keyc; break; }
+                    hh = (hh + 1) & (kClosedTab - 1);
+                }
+                wave_order();
+            } else {
+                uint32_t old = 0;
+                if (lane == 0) old = atomicOr(&closed[cell >> 5], 1u << (cell & 31));
+                old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+                was_closed = (old >> (cell & 31)) & 1u;
+            }
 #ifdef DMPP_DEBUG_SEARCH
             long long tc = clock64(); t_closed += tc - tb;
 #endif
-            if ((old >> (cell & 31)) & 1u) continue;
+            if (was_closed) continue;
             if (lane == 0) {
                 pin[cell] = (uint16_t)(d | (run_in << 4));
                 if (order && n_exp < order_cap) order[n_exp] = cell;
@@ -643,7 +683,11 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
                 double clear = __builtin_inf();
                 for (int j = 0; j < m; j++) {
                     const double dx = p.x - obs[j].x, dy = p.y - obs[j].y;
-                    const double v = sqrt(dx * dx + dy * dy) - (double)obs[j].radius;
+                    const double d2 = dx * dx + dy * dy;
+                    // farther than radius + half width + d_safe: cannot produce a penalty (no sqrt needed)
+                    const double thr = (double)obs[j].radius + half_w + c.d_safe;
+                    if (d2 > thr * thr) continue;
+                    const double v = sqrt(d2) - (double)obs[j].radius;
                     if (v < clear) clear = v;
                 }
                 clear = clear - half_w;

@@ -277,7 +277,11 @@ static void score_one(const PlannerConfig* c, const GlobalPoint2D* p, const ObPo
         double clear = INFINITY;
         for (int j = 0; j < m; j++) {
             double dx = p[i].x - obs[j].x, dy = p[i].y - obs[j].y;
-            double v = sqrt(dx * dx + dy * dy) - (double)obs[j].radius;
+            double d2 = dx * dx + dy * dy;
+            /* an obstacle farther than radius + half width + d_safe cannot produce a penalty: ignored */
+            double thr = (double)obs[j].radius + 0.5 * c->Vehicle_Width + c->d_safe;
+            if (d2 > thr * thr) continue;
+            double v = sqrt(d2) - (double)obs[j].radius;
             if (v < clear) clear = v;
         }
         clear = clear - 0.5 * c->Vehicle_Width;

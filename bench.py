@@ -100,10 +100,11 @@ def main():
         pl.n = n
 
     def barrier():
+        pl.sync()                       # the library's own stream
+        torch.cuda.synchronize()        # everything else on this device
         if dist is not None:
             dist.barrier()
-        pl.sync()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         pl.tick()

@@ -598,11 +598,13 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
 // G3.  256 threads = 4 waves per scene; wave w scores candidates w, w+4, ...
 struct ScoreShared {
     GlobalPoint2D cand[4][DMPP_PATH_POINTS];
+    double seg[4][DMPP_PATH_POINTS];         // |P_i - P_{i+1}| of the wave's current candidate
     GlobalPoint2D pts[DMPP_PATH_POINTS];     // grid-path prefix in metres (lookahead_cells+1 <= 200)
     double cum[DMPP_PATH_POINTS];
-    ObPoint obs[kMaxObsLds];
+    double rx[kMaxObsLds], ry[kMaxObsLds], rr[kMaxObsLds], rt2[kMaxObsLds];   // obstacles that can matter: x, y, radius, cutoff^2
+    double bx0[DMPP_MAX_LATTICE], bx1[DMPP_MAX_LATTICE], by0[DMPP_MAX_LATTICE], by1[DMPP_MAX_LATTICE];
     double cost[DMPP_MAX_LATTICE];
-    int best;
+    int best, n_rel;
 };
 
 __device__ __forceinline__ double wave_tree_sum(double acc)
@@ -626,8 +628,6 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
     const int W = c.grid_w;
     const int m = si.obs_n;
     const ObPoint* gobs = obs_now + si.obs_off;
-    const ObPoint* obs = gobs;
-    if (m <= kMaxObsLds) { for (int j = tid; j < m; j += kBlock) sh.obs[j] = gobs[j]; obs = sh.obs; }
     const int32_t* path = paths + (size_t)scene * c.max_path;
     const GlobalPoint3D ego = si.loc.globalpoint;
     const int status = go.status, path_len = go.path_len;
@@ -661,18 +661,63 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
     __syncthreads();
     const int nl = min(c.n_lattice, DMPP_MAX_LATTICE - 1);
     const int nc = nl + (have_path ? 1 : 0);
+    // the trigonometry is the same for every candidate: start heading, terminal heading
+    const double th0 = ego.dir * c.PI / 180, c0 = cos(th0), s0 = sin(th0);
     const double th = thT * c.PI / 180, cs = cos(th), sn = sin(th);
     const double half_w = 0.5 * c.Vehicle_Width;
+    auto lattice_curve = [&](int k, double& off) -> Bezier {        // BezierPlanning(ego -> terminal k), as bezier_setup
+        off = (double)(k - (nl - 1) / 2) * c.lattice_step;
+        Bezier bz;
+        bz.x0 = ego.x; bz.y0 = ego.y; bz.x3 = T.x + off * sn; bz.y3 = T.y + off * (-cs);
+        const double dx = bz.x3 - bz.x0, dy = bz.y3 - bz.y0;
+        const double d = sqrt(dx * dx + dy * dy) / 3;
+        bz.x1 = bz.x0 + d * c0; bz.y1 = bz.y0 + d * s0;
+        bz.x2 = bz.x3 - d * cs; bz.y2 = bz.y3 - d * sn;
+        return bz;
+    };
+    // ---- obstacles that can matter at all: inside the box of every candidate grown by their cutoff.
+    //      A Bezier lies in the hull of its control points; the grid path stays within a+1 cells of the ego.
+    if (tid < nl) {
+        double off; const Bezier bz = lattice_curve(tid, off);
+        sh.bx0[tid] = fmin(fmin(bz.x0, bz.x1), fmin(bz.x2, bz.x3)); sh.bx1[tid] = fmax(fmax(bz.x0, bz.x1), fmax(bz.x2, bz.x3));
+        sh.by0[tid] = fmin(fmin(bz.y0, bz.y1), fmin(bz.y2, bz.y3)); sh.by1[tid] = fmax(fmax(bz.y0, bz.y1), fmax(bz.y2, bz.y3));
+    }
+    if (tid == 0) sh.n_rel = 0;
+    __syncthreads();
+    double X0 = __builtin_inf(), X1 = -__builtin_inf(), Y0 = __builtin_inf(), Y1 = -__builtin_inf();
+    for (int k = 0; k < nl; k++) { X0 = fmin(X0, sh.bx0[k]); X1 = fmax(X1, sh.bx1[k]); Y0 = fmin(Y0, sh.by0[k]); Y1 = fmax(Y1, sh.by1[k]); }
+    if (have_path) {
+        const double ext = (double)(a + 2) * c.cell;
+        X0 = fmin(X0, ego.x - ext); X1 = fmax(X1, ego.x + ext); Y0 = fmin(Y0, ego.y - ext); Y1 = fmax(Y1, ego.y + ext);
+    }
+    const bool culled = m <= kMaxObsLds;          // longer lists are read from HBM without culling
+    if (culled) {
+        for (int j = tid; j < m; j += kBlock) {
+            const ObPoint o = gobs[j];
+            const double thr = (double)o.radius + half_w + c.d_safe;
+            if (o.x >= X0 - thr && o.x <= X1 + thr && o.y >= Y0 - thr && o.y <= Y1 + thr) {
+                const int q = atomicAdd(&sh.n_rel, 1);           // order is irrelevant: only a minimum is taken
+                sh.rx[q] = o.x; sh.ry[q] = o.y; sh.rr[q] = (double)o.radius; sh.rt2[q] = thr * thr;
+            }
+        }
+    }
+    __syncthreads();
+    const int n_rel = culled ? sh.n_rel : m;
     GlobalPoint2D* cand = sh.cand[wave];
+    double* seg = sh.seg[wave];
     for (int k = wave; k < nc; k += 4) {
         double off = 0;
         if (k < nl) {
-            off = (double)(k - (nl - 1) / 2) * c.lattice_step;
-            GlobalPoint3D e = { T.x + off * sn, T.y + off * (-cs), thT };
-            Bezier bz = bezier_setup(c, ego, e);
+            const Bezier bz = lattice_curve(k, off);
             for (int i = lane; i < DMPP_PATH_POINTS; i += DMPP_WAVE) cand[i] = bezier_point(bz, i, DMPP_PATH_POINTS);
         } else {
             for (int i = lane; i < DMPP_PATH_POINTS; i += DMPP_WAVE) cand[i] = mean_point(c, sh.pts, sh.cum, a + 1, i, DMPP_PATH_POINTS);
+        }
+        wave_sync();
+        // |P_i - P_{i+1}|: the dis1 / dis2 of the circumradius of neighbouring triples, computed once
+        for (int i = lane; i < DMPP_PATH_POINTS - 1; i += DMPP_WAVE) {
+            const GlobalPoint2D p = cand[i], q = cand[i + 1];
+            seg[i] = sqrt((p.x - q.x) * (p.x - q.x) + (p.y - q.y) * (p.y - q.y));
         }
         wave_sync();
         double pen_acc = 0, k2_acc = 0; int first_hit = DMPP_PATH_POINTS;
@@ -681,14 +726,23 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
             if (i < DMPP_PATH_POINTS) {
                 const GlobalPoint2D p = cand[i];
                 double clear = __builtin_inf();
-                for (int j = 0; j < m; j++) {
-                    const double dx = p.x - obs[j].x, dy = p.y - obs[j].y;
-                    const double d2 = dx * dx + dy * dy;
-                    // farther than radius + half width + d_safe: cannot produce a penalty (no sqrt needed)
-                    const double thr = (double)obs[j].radius + half_w + c.d_safe;
-                    if (d2 > thr * thr) continue;
-                    const double v = sqrt(d2) - (double)obs[j].radius;
-                    if (v < clear) clear = v;
+                if (culled) {
+                    for (int j = 0; j < n_rel; j++) {
+                        const double dx = p.x - sh.rx[j], dy = p.y - sh.ry[j];
+                        const double d2 = dx * dx + dy * dy;
+                        if (d2 > sh.rt2[j]) continue;                 // cannot produce a penalty (no sqrt needed)
+                        const double v = sqrt(d2) - sh.rr[j];
+                        if (v < clear) clear = v;
+                    }
+                } else {
+                    for (int j = 0; j < m; j++) {
+                        const double dx = p.x - gobs[j].x, dy = p.y - gobs[j].y;
+                        const double d2 = dx * dx + dy * dy;
+                        const double thr = (double)gobs[j].radius + half_w + c.d_safe;
+                        if (d2 > thr * thr) continue;
+                        const double v = sqrt(d2) - (double)gobs[j].radius;
+                        if (v < clear) clear = v;
+                    }
                 }
                 clear = clear - half_w;
                 double pen;
@@ -697,7 +751,17 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
                 else pen = 0;
                 pen_acc += pen;
                 if (i >= 1 && i <= DMPP_PATH_POINTS - 2) {
-                    const double R = radius3_fenced(cand[i - 1], p, cand[i + 1]);
+                    // radius3_fenced(P[i-1], P[i], P[i+1]) with dis1 = seg[i-1], dis2 = seg[i]
+                    const GlobalPoint2D pa = cand[i - 1], pf = cand[i + 1];
+                    const double dis1 = seg[i - 1], dis2 = seg[i];
+                    const double dis3 = sqrt((pa.x - pf.x) * (pa.x - pf.x) + (pa.y - pf.y) * (pa.y - pf.y));
+                    const double den = 2 * dis1 * dis2;
+                    double R = 1000;
+                    if (den > 0) {
+                        const double cosA = (dis1 * dis1 + dis2 * dis2 - dis3 * dis3) / den;
+                        const double sinA = sqrt(1 - cosA * cosA);
+                        if (sinA >= 0.001) R = 0.5 * dis3 / sinA;
+                    }
                     const double kk = 1 / R;
                     k2_acc += kk * kk;
                 }
@@ -724,9 +788,7 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
         if (tid < DMPP_PATH_POINTS) {
             GlobalPoint2D p;
             if (k < nl) {
-                const double off = (double)(k - (nl - 1) / 2) * c.lattice_step;
-                GlobalPoint3D e = { T.x + off * sn, T.y + off * (-cs), thT };
-                Bezier bz = bezier_setup(c, ego, e);
+                double off; const Bezier bz = lattice_curve(k, off);
                 p = bezier_point(bz, tid, DMPP_PATH_POINTS);
             } else p = mean_point(c, sh.pts, sh.cum, a + 1, tid, DMPP_PATH_POINTS);
             go.best_path[tid] = p;

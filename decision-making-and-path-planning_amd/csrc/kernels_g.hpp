@@ -293,6 +293,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     __shared__ uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24
     __shared__ uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
     __shared__ uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
+    __shared__ int j_view[16], j_line[16], j_pos[16], j_sgn[16], j_run[16];   // the straight jumps of the current step
     __shared__ uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
@@ -341,9 +342,6 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     const int cap = min(c.bucket_cap, kOpenCap);
     int status = -1, n_exp = 0, n_push = 0, n_rounds = 0, path_cost = 0;
     uint64_t digest = 0;
-#ifdef DMPP_DEBUG_SEARCH
-    long long t0 = clock64(), t_pop = 0, t_closed = 0, t_jump = 0, t_push = 0, t_loaded = 0, t_done = 0; int c_iter = 0, c_jh = 0, c_jv = 0, c_scan = 0, c_compact = 0;
-#endif
 
     if ((bm[goal >> 5] >> (goal & 31)) & 1u) {
         status = DMPP_G_GOAL_BLOCKED;
@@ -362,134 +360,156 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         Bits<GBM> B{ bm, W, H, WW };     // single-cell tests of the diagonal steps
         int n_open = 1, live = 1, fmax = -1;
         n_push = 1;
-        // lanes 0..7 = the eight directions of the node being expanded
+        // jobs of jw lanes (jw*32 cells must cover a whole line): 4 per pass at <= 512, 2 at <= 1024, 1 above
+        const int jw_log = (WW <= 16 && HW <= 16) ? 4 : ((WW <= 32 && HW <= 32) ? 5 : 6);
+        const int jw = 1 << jw_log, njpp = DMPP_WAVE >> jw_log;
+        // lane = node * 8 + s: the eight directions of each of the (<= 4) nodes of a step
         const int s = lane & 7;
         const int sdx = (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0);
         const int sdy = (s >= 1 && s <= 3) ? 1 : ((s >= 5) ? -1 : 0);
         long long guard = 16ll * N + 1024;                 // every iteration pops an entry; entries <= 8 per closed cell
-#ifdef DMPP_DEBUG_SEARCH
-        t_loaded = clock64();
-#endif
         while (status < 0) {
             if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
-#ifdef DMPP_DEBUG_SEARCH
-            c_iter++; long long ta = clock64(); c_scan += (n_open + 63) / 64;
-#endif
             if (live == 0) { status = DMPP_G_NO_PATH; break; }
-            // ---- pop: smallest f, ties to the latest push ----
-            uint32_t key = 0xFFFFFFFFu;
-            for (int i = lane; i < n_open; i += DMPP_WAVE) {
-                const uint32_t f2 = o_f2[i];
-                if (f2 != 0xFFFFu) { const uint32_t k = (f2 << 16) | (uint32_t)(0xFFFF - i); if (k < key) key = k; }
+            // ---- pop: up to 4 entries of the smallest f, the latest pushes first ----
+            uint32_t key = 0xFFFFu;
+            for (int i = lane; i < n_open; i += DMPP_WAVE) { const uint32_t f2 = o_f2[i]; if (f2 < key) key = f2; }
+            const uint32_t fmin2 = wave_min_u32(key);
+            if (fmin2 == 0xFFFFu) { status = DMPP_G_INTERNAL; break; }
+            const int f = (int)fmin2 << 1;
+            int nt = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+            for (int c0 = ((n_open - 1) >> 6) << 6; c0 >= 0 && nt < DMPP_JPS_BATCH; c0 -= DMPP_WAVE) {
+                const int i = c0 + lane;
+                unsigned long long tm = __ballot(i < n_open && o_f2[i] == fmin2);
+                while (tm && nt < DMPP_JPS_BATCH) {
+                    const int L = 63 - __clzll((long long)tm);
+                    tm &= ~(1ull << L);
+                    const int idx = c0 + L;
+                    if (nt == 0) i0 = idx; else if (nt == 1) i1 = idx; else if (nt == 2) i2 = idx; else i3 = idx;
+                    nt++;
+                }
             }
-            key = wave_min_u32(key);
-            const int bi = 0xFFFF - (int)(key & 0xFFFFu), f = (int)(key >> 16) << 1;
-            const uint32_t e = o_ent[bi];
-            const int run_in = o_run[bi];
+            const int myi = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : i3;
+            const bool have = lane < nt;
+            uint32_t e = 0; int run_in = 0;
+            if (have) { e = o_ent[myi]; run_in = o_run[myi]; }
             wave_order();
-            if (lane == 0) o_f2[bi] = 0xFFFFu;
-            live--;
-            if (bi == n_open - 1) n_open--;
+            if (have) o_f2[myi] = 0xFFFFu;
+            live -= nt;
+            if (i0 == n_open - 1) n_open--;
             const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu), d = (int)(e >> 24);
             const int cell = y * W + x;
-#ifdef DMPP_DEBUG_SEARCH
-            long long tb = clock64(); t_pop += tb - ta;
-#endif
-            // ---- closed?  The HBM bit set always gets the bit (fire and forget); the answer comes from
-            //      the LDS hash while it has room, from the returning HBM atomic afterwards ----
-            bool was_closed;
-            if (n_exp < kClosedMax) {
-                if (lane == 0) atomicOr(&closed[cell >> 5], 1u << (cell & 31));
-                const uint32_t keyc = (uint32_t)cell + 1u;
-                uint32_t hh = ((uint32_t)cell * 2654435761u) >> 21;
-                was_closed = false;
-                for (int probe = 0; probe < kClosedTab; probe++) {
-                    const uint32_t v = c_tab[hh];
-                    if (v == keyc) { was_closed = true; break; }
-                    if (v == 0) { if (lane == 0) c_tab[hh] = keyc; break; }
-                    hh = (hh + 1) & (kClosedTab - 1);
+            // ---- closed?  duplicates inside the batch: the earlier one wins; then the closed set ----
+            bool valid = have;
+            {
+                const int c0_ = __builtin_amdgcn_readlane(cell, 0), c1_ = __builtin_amdgcn_readlane(cell, 1), c2_ = __builtin_amdgcn_readlane(cell, 2);
+                if ((lane == 1 && cell == c0_) || (lane == 2 && (cell == c0_ || cell == c1_)) ||
+                    (lane == 3 && (cell == c0_ || cell == c1_ || cell == c2_))) valid = false;
+            }
+            if (n_exp + DMPP_JPS_BATCH <= kClosedMax) {
+                if (valid) {
+                    atomicOr(&closed[cell >> 5], 1u << (cell & 31));          // the HBM set stays complete (fire and forget)
+                    const uint32_t keyc = (uint32_t)cell + 1u;
+                    uint32_t hh = ((uint32_t)cell * 2654435761u) >> 21;
+                    for (int probe = 0; probe < kClosedTab; probe++) {
+                        const uint32_t old = atomicCAS(&c_tab[hh], 0u, keyc);
+                        if (old == 0u) break;                                 // inserted: was open
+                        if (old == keyc) { valid = false; break; }            // already closed
+                        hh = (hh + 1) & (kClosedTab - 1);
+                    }
                 }
-                wave_order();
-            } else {
-                uint32_t old = 0;
-                if (lane == 0) old = atomicOr(&closed[cell >> 5], 1u << (cell & 31));
-                old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
-                was_closed = (old >> (cell & 31)) & 1u;
+            } else if (valid) {
+                const uint32_t old = atomicOr(&closed[cell >> 5], 1u << (cell & 31));
+                if ((old >> (cell & 31)) & 1u) valid = false;
             }
-#ifdef DMPP_DEBUG_SEARCH
-            long long tc = clock64(); t_closed += tc - tb;
-#endif
-            if (was_closed) continue;
-            if (lane == 0) {
+            // the goal, or the entry that reaches the expansion limit, ends the search at once
+            unsigned vm = (unsigned)__ballot(valid) & 0xFu;
+            {
+                const int nvb = __popc(vm & ((1u << lane) - 1u));
+                const unsigned stop = (unsigned)__ballot(valid && (cell == goal || n_exp + nvb + 1 >= c.max_expansions)) & 0xFu;
+                if (stop) {
+                    const int last = __ffs((int)stop) - 1;
+                    if (lane > last) valid = false;
+                    vm = (unsigned)__ballot(valid) & 0xFu;
+                }
+            }
+            if (valid) {
+                const int seq = n_exp + __popc(vm & ((1u << lane) - 1u));
                 pin[cell] = (uint16_t)(d | (run_in << 4));
-                if (order && n_exp < order_cap) order[n_exp] = cell;
-                digest += mix64(((uint64_t)(uint32_t)n_exp << 32) | (uint32_t)cell);
+                if (order && seq < order_cap) order[seq] = cell;
+                digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell);
             }
-            if (f > fmax) { fmax = f; n_rounds++; }
-            n_exp++;
-            if (cell == goal) { status = DMPP_G_FOUND; path_cost = f; break; }
+            if (vm && f > fmax) { fmax = f; n_rounds++; }
+            n_exp += __popc(vm);
+            if (__ballot(valid && cell == goal)) { status = DMPP_G_FOUND; path_cost = f; break; }
             if (n_exp >= c.max_expansions) { status = DMPP_G_LIMIT; break; }
-            // ---- successors, direction s on lane s (s < 8): branch-free form of the rule table ----
-            const int gcur = f - hfun(x, y, gx, gy);
+            if (vm == 0) continue;
+            // ---- successors: lane = node * 8 + s for the (<= 4) batch nodes ----
+            const int node = lane >> 3;
+            const int nx0 = __shfl(x, node, 64), ny0 = __shfl(y, node, 64), nd = __shfl(d, node, 64);
+            const bool nvalid = lane < 32 && ((vm >> node) & 1u);
+            const int gcur = f - hfun(nx0, ny0, gx, gy);
             bool want_jump = false; int run = 0;
             {
-                const int dd = d & 7;
+                const int dd = nd & 7;
                 const int ddx = (dd == 0 || dd == 1 || dd == 7) ? 1 : ((dd >= 3 && dd <= 5) ? -1 : 0);
                 const int ddy = (dd >= 1 && dd <= 3) ? 1 : ((dd >= 5) ? -1 : 0);
-                const int rel = (s - d) & 7;
-                const bool is_start = d == 8, d_odd = (d & 1) != 0 && !is_start, d_even = !d_odd && !is_start;
-                want_jump = lane < 8 && ((is_start && (s & 1) == 0) || (d_even && rel == 0) || (d_odd && (rel == 1 || rel == 7)));
-                const bool plain = lane < 8 && ((is_start && (s & 1) != 0) || (d_odd && rel == 0));
-                const bool sided = lane < 8 && ((d_even && (rel == 1 || rel == 7)) || (d_odd && (rel == 2 || rel == 6)));
-                // the cell beside p on the side direction s leans to: (s - d) for a straight d, (s - d)/2 for a diagonal d
+                const int rel = (s - nd) & 7;
+                const bool is_start = nd == 8, d_odd = (nd & 1) != 0 && !is_start, d_even = !d_odd && !is_start;
+                want_jump = nvalid && ((is_start && (s & 1) == 0) || (d_even && rel == 0) || (d_odd && (rel == 1 || rel == 7)));
+                const bool plain = nvalid && ((is_start && (s & 1) != 0) || (d_odd && rel == 0));
+                const bool sided = nvalid && ((d_even && (rel == 1 || rel == 7)) || (d_odd && (rel == 2 || rel == 6)));
                 const int px = d_odd ? (sdx - ddx) / 2 : sdx - ddx, py = d_odd ? (sdy - ddy) / 2 : sdy - ddy;
-                const bool t_free = (plain || sided) && !B.blk(x + sdx, y + sdy);
-                const bool side_blk = sided && B.blk(x + px, y + py);
+                const bool t_free = (plain || sided) && !B.blk(nx0 + sdx, ny0 + sdy);
+                const bool side_blk = sided && B.blk(nx0 + px, ny0 + py);
                 if ((plain && t_free) || (sided && side_blk && t_free)) run = 1;
             }
-            unsigned jm = (unsigned)__ballot(want_jump) & 0xFFu;
-            while (jm) {
-                // up to two of the wanted jumps per pass (E/W on the row view, N/S on the column view)
-                const int ja = __ffs((int)jm) - 1; jm &= jm - 1;
-                int jb = -1;
-                if (jm && WW <= 32 && HW <= 32) { jb = __ffs((int)jm) - 1; jm &= jm - 1; }
-                LineJob A, Bj;
-                {
-                    const bool horiz = ja == 0 || ja == 4;
-                    A.base = horiz ? bm : bmT; A.LW = horiz ? WW : HW; A.NL = horiz ? H : W;
-                    A.line = horiz ? y : x; A.pos = horiz ? x : y; A.sgn = (ja == 0 || ja == 2) ? 1 : -1;
-                    A.gline = horiz ? gy : gx; A.gpos = horiz ? gx : gy; A.active = true;
-                }
-                {
-                    const int jj = jb < 0 ? 0 : jb;
-                    const bool horiz = jj == 0 || jj == 4;
-                    Bj.base = horiz ? bm : bmT; Bj.LW = horiz ? WW : HW; Bj.NL = horiz ? H : W;
-                    Bj.line = horiz ? y : x; Bj.pos = horiz ? x : y; Bj.sgn = (jj == 0 || jj == 2) ? 1 : -1;
-                    Bj.gline = horiz ? gy : gx; Bj.gpos = horiz ? gx : gy; Bj.active = jb >= 0;
-                }
-                int ra = 0, rb = 0;
-                if (WW <= 32 && HW <= 32) wave_jump_pair(A, Bj, lane, ra, rb);
-                else ra = wave_jump_one(A, lane);
-                if (lane == ja) run = ra;
-                if (jb >= 0 && lane == jb) run = rb;
+            // ---- every straight jump of the step is a job; jobs share passes, jw lanes each ----
+            const unsigned long long jm = __ballot(want_jump);
+            const int njobs = __popcll(jm);
+            int myjob = -1;
+            if (want_jump) {
+                myjob = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(jm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)jm, 0u));
+                const bool horiz = s == 0 || s == 4;
+                j_view[myjob] = horiz ? 0 : 1;
+                j_line[myjob] = horiz ? ny0 : nx0;
+                j_pos[myjob] = horiz ? nx0 : ny0;
+                j_sgn[myjob] = (s == 0 || s == 2) ? 1 : -1;
             }
-#ifdef DMPP_DEBUG_SEARCH
-            long long td = clock64(); t_jump += td - tc;
-#endif
-            // ---- push in direction order ----
-            const bool push = lane < 8 && run > 0;
-            const unsigned pm = (unsigned)__ballot(push) & 0xFFu;
+            wave_order();
+            for (int p0 = 0; p0 < njobs; p0 += njpp) {
+                const int grp = lane >> jw_log, gl = lane & (jw - 1), job = p0 + grp;
+                LineJob J;
+                J.active = job < njobs;
+                const int jj = J.active ? job : 0;
+                const bool jv = j_view[jj] != 0;
+                J.base = jv ? bmT : bm; J.LW = jv ? HW : WW; J.NL = jv ? W : H;
+                J.line = j_line[jj]; J.pos = j_pos[jj]; J.sgn = j_sgn[jj];
+                J.gline = jv ? gx : gy; J.gpos = jv ? gy : gx;
+                uint32_t B0 = 0, stop = 0;
+                if (J.active) stop = line_stop(J, gl, B0);
+                const unsigned long long m = __ballot(stop != 0);
+                const unsigned long long gmask = jw == 64 ? m : ((m >> (grp << jw_log)) & ((1ull << jw) - 1ull));
+                int r = 0;
+                const int L = gmask ? __ffsll((long long)gmask) - 1 : 0;
+                const uint32_t wsel = (uint32_t)__shfl((int)stop, (grp << jw_log) + L, 64);
+                const uint32_t bsel = (uint32_t)__shfl((int)B0, (grp << jw_log) + L, 64);
+                if (gmask) r = line_run(J, L, wsel, bsel);
+                if (J.active && gl == 0) j_run[job] = r;
+                wave_order();
+            }
+            if (want_jump) run = j_run[myjob];
+            // ---- push in batch order, then direction order ----
+            const bool push = run > 0;
+            const unsigned pm = (unsigned)__ballot(push);
             const int cnt = __popc(pm);
             if (cnt) {
                 if (live + cnt > cap) { status = DMPP_G_OVERFLOW; break; }
                 if (n_open + cnt > kOpenCap) {
-#ifdef DMPP_DEBUG_SEARCH
-                    c_compact++;
-#endif
                     // squeeze the dead slots out, keeping the push order (ballot + prefix popcount)
                     int w = 0;
-                    for (int i0 = 0; i0 < n_open; i0 += DMPP_WAVE) {
-                        const int i = i0 + lane;
+                    for (int q0 = 0; q0 < n_open; q0 += DMPP_WAVE) {
+                        const int i = q0 + lane;
                         uint32_t f2 = 0xFFFFu, ee = 0; uint16_t rr = 0;
                         if (i < n_open) { f2 = o_f2[i]; ee = o_ent[i]; rr = o_run[i]; }
                         const bool alive = f2 != 0xFFFFu;
@@ -505,7 +525,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                     n_open = w;
                 }
                 if (push) {
-                    const int nx = x + run * sdx, ny = y + run * sdy;
+                    const int nx = nx0 + run * sdx, ny = ny0 + run * sdy;
                     const int fn = gcur + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
                     const int slot = n_open + __popc(pm & ((1u << lane) - 1u));
                     o_f2[slot] = (uint16_t)(fn >> 1);
@@ -515,15 +535,9 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 n_open += cnt; live += cnt; n_push += cnt;
                 wave_order();
             }
-#ifdef DMPP_DEBUG_SEARCH
-            t_push += clock64() - td;
-#endif
         }
     }
 
-#ifdef DMPP_DEBUG_SEARCH
-    t_done = clock64();
-#endif
     // ---- reduce the digest, rebuild the path from the runs, publish ----
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) {
@@ -584,10 +598,6 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             }
         }
     }
-#ifdef DMPP_DEBUG_SEARCH
-    if (lane == 0) { long long te = clock64(); int32_t* dbg = path + c.max_path - 16; dbg[0] = c_iter; dbg[1] = c_jh; dbg[2] = c_jv; dbg[3] = c_scan; dbg[4] = c_compact;
-        dbg[5] = (int)((t_loaded - t0) >> 4); dbg[6] = (int)(t_pop >> 4); dbg[7] = (int)(t_closed >> 4); dbg[8] = (int)(t_jump >> 4); dbg[9] = (int)(t_push >> 4); dbg[10] = (int)((te - t_done) >> 4); dbg[11] = (int)((te - t0) >> 4); }
-#endif
     if (lane == 0) {
         go.order_digest = digest; go.status = status; go.n_expanded = n_exp; go.n_pushed = n_push; go.n_rounds = n_rounds;
         go.path_len = path_len; go.path_cost = path_cost; go.start_cell = start; go.goal_cell = goal;

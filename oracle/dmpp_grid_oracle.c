@@ -92,10 +92,16 @@ void orc_rasterise(const PlannerConfig* c, GlobalPoint2D origin, const ObPoint* 
  *                          only if forced: the cell beside p on that side is blocked and p+s is free;
  *             d diagonal : s = d+-1 (its two straight components) -> jump(p,s);  s = d -> p+s if free;
  *                          s = d+-2 -> p+s only if forced: the cell p + (s-d)/2 is blocked and p+s free.
- *   open set: a list in push order; an entry is (f, cell, arriving direction, run length).  Pop the
- *             smallest f, ties to the most recently pushed; an entry whose cell is already closed is
- *             dropped.  The k-th cell closed is expansion k.  g is recovered as f - h(cell).
- *   stop    : goal closed (FOUND) | open set empty (NO_PATH) | n_expanded == max_expansions (LIMIT)
+ *   open set: a list in push order; an entry is (f, cell, arriving direction, run length); g is
+ *             recovered as f - h(cell).
+ *   step    : let fmin be the smallest f in the open set.  Up to DMPP_JPS_BATCH (4) entries with
+ *             f = fmin are taken, the most recently pushed first; an entry whose cell is already closed
+ *             is dropped, the others are closed in that order (the k-th cell closed is expansion k) and
+ *             form the batch.  Then the batch nodes, in that order, push their successors (s = 0..7).
+ *             Every batch node has the minimal f, so its g is final: the search stays optimal while a
+ *             64-lane wave expands four nodes at once.
+ *   stop    : goal closed (FOUND, at once: the rest of the step is skipped) | open set empty (NO_PATH)
+ *             | n_expanded == max_expansions (LIMIT, at once)
  *             | more than open_cap = min(bucket_cap, DMPP_OPEN_CAP) live entries (OVERFLOW).
  *   path    : from the goal, each closed cell knows its arriving direction and run length; the cells
  *             of every run are written out, start..goal.
@@ -168,47 +174,58 @@ void orc_grid_search(const PlannerConfig* c, const uint8_t* grid, int start_cell
     int status = -1, fmax = -1;
     while (status < 0) {
         if (n_open == 0) { status = DMPP_G_NO_PATH; break; }
-        int bi = 0;
-        for (int i = 1; i < n_open; i++) if (open[i].f <= open[bi].f) bi = i;       /* smallest f, latest push */
-        OEnt e = open[bi];
-        memmove(&open[bi], &open[bi + 1], sizeof(OEnt) * (size_t)(n_open - bi - 1));  /* keeps push order */
-        n_open--;
-        if (closed[e.cell]) continue;
-        closed[e.cell] = 1; pdir[e.cell] = (uint8_t)e.dir; prun[e.cell] = (uint16_t)e.run;
-        if (e.f > fmax) { fmax = e.f; out->n_rounds++; }
-        int seq = out->n_expanded++;
-        if (order && seq < order_cap) order[seq] = e.cell;
-        out->order_digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)e.cell);
-        if (e.cell == goal_cell) { status = DMPP_G_FOUND; out->path_cost = e.f; break; }
-        if (out->n_expanded >= c->max_expansions) { status = DMPP_G_LIMIT; break; }
-        const int x = e.cell % W, y = e.cell / W, d = e.dir;
-        const int g = e.f - hfun(x, y, gx, gy);
-        for (int s = 0; s < 8 && status < 0; s++) {
-            int run = 0;                                   /* 0 = no successor in direction s */
-            const int tx = x + DX[s], ty = y + DY[s];
-            if (d == 8) {
-                if ((s & 1) == 0) run = jump_straight(&G, x, y, s, gx, gy);
-                else if (!jblk(&G, tx, ty)) run = 1;
-            } else if ((d & 1) == 0) {
-                if (s == d) run = jump_straight(&G, x, y, s, gx, gy);
-                else if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) {
-                    const int px = DX[s] - DX[d], py = DY[s] - DY[d];          /* the side the diagonal leans to */
-                    if (jblk(&G, x + px, y + py) && !jblk(&G, tx, ty)) run = 1;
+        int fmin = open[0].f;
+        for (int i = 1; i < n_open; i++) if (open[i].f < fmin) fmin = open[i].f;
+        OEnt batch[DMPP_JPS_BATCH]; int nb = 0;
+        for (int t = 0; t < DMPP_JPS_BATCH && status < 0; t++) {
+            int bi = -1;
+            for (int i = n_open - 1; i >= 0; i--) if (open[i].f == fmin) { bi = i; break; }    /* latest push first */
+            if (bi < 0) break;
+            OEnt e = open[bi];
+            memmove(&open[bi], &open[bi + 1], sizeof(OEnt) * (size_t)(n_open - bi - 1));        /* keeps push order */
+            n_open--;
+            if (closed[e.cell]) continue;
+            closed[e.cell] = 1; pdir[e.cell] = (uint8_t)e.dir; prun[e.cell] = (uint16_t)e.run;
+            if (e.f > fmax) { fmax = e.f; out->n_rounds++; }
+            int seq = out->n_expanded++;
+            if (order && seq < order_cap) order[seq] = e.cell;
+            out->order_digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)e.cell);
+            batch[nb++] = e;
+            if (e.cell == goal_cell) { status = DMPP_G_FOUND; out->path_cost = e.f; }
+            else if (out->n_expanded >= c->max_expansions) status = DMPP_G_LIMIT;
+        }
+        if (status >= 0) break;
+        for (int bn = 0; bn < nb && status < 0; bn++) {
+            const OEnt e = batch[bn];
+            const int x = e.cell % W, y = e.cell / W, d = e.dir;
+            const int g = e.f - hfun(x, y, gx, gy);
+            for (int s = 0; s < 8 && status < 0; s++) {
+                int run = 0;                                   /* 0 = no successor in direction s */
+                const int tx = x + DX[s], ty = y + DY[s];
+                if (d == 8) {
+                    if ((s & 1) == 0) run = jump_straight(&G, x, y, s, gx, gy);
+                    else if (!jblk(&G, tx, ty)) run = 1;
+                } else if ((d & 1) == 0) {
+                    if (s == d) run = jump_straight(&G, x, y, s, gx, gy);
+                    else if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) {
+                        const int px = DX[s] - DX[d], py = DY[s] - DY[d];          /* the side the diagonal leans to */
+                        if (jblk(&G, x + px, y + py) && !jblk(&G, tx, ty)) run = 1;
+                    }
+                } else {
+                    if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) run = jump_straight(&G, x, y, s, gx, gy);
+                    else if (s == d) { if (!jblk(&G, tx, ty)) run = 1; }
+                    else if (s == ((d + 2) & 7) || s == ((d + 6) & 7)) {
+                        const int px = (DX[s] - DX[d]) / 2, py = (DY[s] - DY[d]) / 2;
+                        if (jblk(&G, x + px, y + py) && !jblk(&G, tx, ty)) run = 1;
+                    }
                 }
-            } else {
-                if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) run = jump_straight(&G, x, y, s, gx, gy);
-                else if (s == d) { if (!jblk(&G, tx, ty)) run = 1; }
-                else if (s == ((d + 2) & 7) || s == ((d + 6) & 7)) {
-                    const int px = (DX[s] - DX[d]) / 2, py = (DY[s] - DY[d]) / 2;
-                    if (jblk(&G, x + px, y + py) && !jblk(&G, tx, ty)) run = 1;
-                }
+                if (!run) continue;
+                const int nx = x + run * DX[s], ny = y + run * DY[s];
+                const int fn = g + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
+                if (n_open >= cap) { status = DMPP_G_OVERFLOW; break; }
+                open[n_open++] = (OEnt){ fn, ny * W + nx, s, run };
+                out->n_pushed++;
             }
-            if (!run) continue;
-            const int nx = x + run * DX[s], ny = y + run * DY[s];
-            const int fn = g + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
-            if (n_open >= cap) { status = DMPP_G_OVERFLOW; break; }
-            open[n_open++] = (OEnt){ fn, ny * W + nx, s, run };
-            out->n_pushed++;
         }
     }
     out->status = status;

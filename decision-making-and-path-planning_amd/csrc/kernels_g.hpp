@@ -192,7 +192,7 @@ struct LineJob {
 };
 __device__ __forceinline__ uint32_t view_word(const LineJob& J, int line, int w)
 {
-    const bool ok = line >= 0 && line < J.NL && w >= 0 && w < J.LW;
+    const bool ok = (unsigned)line < (unsigned)J.NL && (unsigned)w < (unsigned)J.LW;
     const uint32_t v = J.base[ok ? line * J.LW + w : 0];
     return ok ? v : 0xFFFFFFFFu;
 }
@@ -342,6 +342,9 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     const int cap = min(c.bucket_cap, kOpenCap);
     int status = -1, n_exp = 0, n_push = 0, n_rounds = 0, path_cost = 0;
     uint64_t digest = 0;
+#ifdef DMPP_DEBUG_SEARCH
+    long long t0 = clock64(), t_pop = 0, t_closed = 0, t_cand = 0, t_jump = 0, t_push = 0, t_done = 0; int c_iter = 0, c_jobs = 0, c_pass = 0, c_scan = 0, c_nt = 0;
+#endif
 
     if ((bm[goal >> 5] >> (goal & 31)) & 1u) {
         status = DMPP_G_GOAL_BLOCKED;
@@ -370,17 +373,48 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         long long guard = 16ll * N + 1024;                 // every iteration pops an entry; entries <= 8 per closed cell
         while (status < 0) {
             if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
+#ifdef DMPP_DEBUG_SEARCH
+            c_iter++; long long ta = clock64(); c_scan += (n_open + 63) / 64;
+#endif
             if (live == 0) { status = DMPP_G_NO_PATH; break; }
             // ---- pop: up to 4 entries of the smallest f, the latest pushes first ----
-            uint32_t key = 0xFFFFu;
-            for (int i = lane; i < n_open; i += DMPP_WAVE) { const uint32_t f2 = o_f2[i]; if (f2 < key) key = f2; }
+            // (1) squeeze the dead slots out when they outnumber the live ones: the scans below stay short
+            if (n_open - live > 64 && n_open > 2 * live) {
+                int w = 0;
+                for (int q0 = 0; q0 < n_open; q0 += DMPP_WAVE) {
+                    const int i = q0 + lane;
+                    uint32_t f2 = 0xFFFFu, ee = 0; uint16_t rr = 0;
+                    if (i < n_open) { f2 = o_f2[i]; ee = o_ent[i]; rr = o_run[i]; }
+                    const bool alive = f2 != 0xFFFFu;
+                    const unsigned long long am = __ballot(alive);
+                    wave_order();
+                    if (alive) {
+                        const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+                        o_f2[w + r] = (uint16_t)f2; o_ent[w + r] = ee; o_run[w + r] = rr;
+                    }
+                    w += __popcll(am);
+                    wave_order();
+                }
+                n_open = w;
+            }
+            // (2) the first 256 slots are cached in registers: one LDS pass serves both the minimum and the ties
+            uint32_t v0 = 0xFFFFu, v1 = 0xFFFFu, v2 = 0xFFFFu, v3 = 0xFFFFu;
+            if (lane < n_open) v0 = o_f2[lane];
+            if (lane + 64 < n_open) v1 = o_f2[lane + 64];
+            if (lane + 128 < n_open) v2 = o_f2[lane + 128];
+            if (lane + 192 < n_open) v3 = o_f2[lane + 192];
+            uint32_t key = min(min(v0, v1), min(v2, v3));
+            for (int i = lane + 256; i < n_open; i += DMPP_WAVE) { const uint32_t f2 = o_f2[i]; if (f2 < key) key = f2; }
             const uint32_t fmin2 = wave_min_u32(key);
             if (fmin2 == 0xFFFFu) { status = DMPP_G_INTERNAL; break; }
             const int f = (int)fmin2 << 1;
             int nt = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
             for (int c0 = ((n_open - 1) >> 6) << 6; c0 >= 0 && nt < DMPP_JPS_BATCH; c0 -= DMPP_WAVE) {
                 const int i = c0 + lane;
-                unsigned long long tm = __ballot(i < n_open && o_f2[i] == fmin2);
+                bool tie;
+                if (c0 == 0) tie = v0 == fmin2; else if (c0 == 64) tie = v1 == fmin2; else if (c0 == 128) tie = v2 == fmin2;
+                else if (c0 == 192) tie = v3 == fmin2; else tie = i < n_open && o_f2[i] == fmin2;
+                unsigned long long tm = __ballot(tie);
                 while (tm && nt < DMPP_JPS_BATCH) {
                     const int L = 63 - __clzll((long long)tm);
                     tm &= ~(1ull << L);
@@ -399,6 +433,9 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             if (i0 == n_open - 1) n_open--;
             const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu), d = (int)(e >> 24);
             const int cell = y * W + x;
+#ifdef DMPP_DEBUG_SEARCH
+            long long tb = clock64(); t_pop += tb - ta; c_nt += nt;
+#endif
             // ---- closed?  duplicates inside the batch: the earlier one wins; then the closed set ----
             bool valid = have;
             {
@@ -444,6 +481,9 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             if (__ballot(valid && cell == goal)) { status = DMPP_G_FOUND; path_cost = f; break; }
             if (n_exp >= c.max_expansions) { status = DMPP_G_LIMIT; break; }
             if (vm == 0) continue;
+#ifdef DMPP_DEBUG_SEARCH
+            long long tc = clock64(); t_closed += tc - tb;
+#endif
             // ---- successors: lane = node * 8 + s for the (<= 4) batch nodes ----
             const int node = lane >> 3;
             const int nx0 = __shfl(x, node, 64), ny0 = __shfl(y, node, 64), nd = __shfl(d, node, 64);
@@ -464,6 +504,9 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 const bool side_blk = sided && B.blk(nx0 + px, ny0 + py);
                 if ((plain && t_free) || (sided && side_blk && t_free)) run = 1;
             }
+#ifdef DMPP_DEBUG_SEARCH
+            long long td = clock64(); t_cand += td - tc;
+#endif
             // ---- every straight jump of the step is a job; jobs share passes, jw lanes each ----
             const unsigned long long jm = __ballot(want_jump);
             const int njobs = __popcll(jm);
@@ -490,15 +533,18 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 if (J.active) stop = line_stop(J, gl, B0);
                 const unsigned long long m = __ballot(stop != 0);
                 const unsigned long long gmask = jw == 64 ? m : ((m >> (grp << jw_log)) & ((1ull << jw) - 1ull));
-                int r = 0;
-                const int L = gmask ? __ffsll((long long)gmask) - 1 : 0;
-                const uint32_t wsel = (uint32_t)__shfl((int)stop, (grp << jw_log) + L, 64);
-                const uint32_t bsel = (uint32_t)__shfl((int)B0, (grp << jw_log) + L, 64);
-                if (gmask) r = line_run(J, L, wsel, bsel);
-                if (J.active && gl == 0) j_run[job] = r;
+                // the lane holding the first stop of its group turns it into the run length itself
+                const int L = gmask ? __ffsll((long long)gmask) - 1 : -1;
+                if (J.active) {
+                    if (gl == L) j_run[job] = line_run(J, gl, stop, B0);
+                    else if (L < 0 && gl == 0) j_run[job] = 0;            // ran off the edge of the grid
+                }
                 wave_order();
             }
             if (want_jump) run = j_run[myjob];
+#ifdef DMPP_DEBUG_SEARCH
+            long long te2 = clock64(); t_jump += te2 - td; c_jobs += njobs; c_pass += (njobs + njpp - 1) / njpp;
+#endif
             // ---- push in batch order, then direction order ----
             const bool push = run > 0;
             const unsigned pm = (unsigned)__ballot(push);
@@ -535,9 +581,15 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 n_open += cnt; live += cnt; n_push += cnt;
                 wave_order();
             }
+#ifdef DMPP_DEBUG_SEARCH
+            t_push += clock64() - te2;
+#endif
         }
     }
 
+#ifdef DMPP_DEBUG_SEARCH
+    t_done = clock64();
+#endif
     // ---- reduce the digest, rebuild the path from the runs, publish ----
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) {
@@ -598,6 +650,10 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             }
         }
     }
+#ifdef DMPP_DEBUG_SEARCH
+    if (lane == 0) { long long te = clock64(); int32_t* dbg = path + c.max_path - 16; dbg[0] = c_iter; dbg[1] = c_nt; dbg[2] = c_jobs; dbg[3] = c_pass; dbg[4] = c_scan;
+        dbg[5] = (int)(t_pop >> 4); dbg[6] = (int)(t_closed >> 4); dbg[7] = (int)(t_cand >> 4); dbg[8] = (int)(t_jump >> 4); dbg[9] = (int)(t_push >> 4); dbg[10] = (int)((te - t_done) >> 4); dbg[11] = (int)((te - t0) >> 4); }
+#endif
     if (lane == 0) {
         go.order_digest = digest; go.status = status; go.n_expanded = n_exp; go.n_pushed = n_push; go.n_rounds = n_rounds;
         go.path_len = path_len; go.path_cost = path_cost; go.start_cell = start; go.goal_cell = goal;

@@ -14,7 +14,7 @@ for s in range(n):
     p=pl.get_path(s, mp)[-16:]
     rows.append([int(g['n_expanded'][s]), int(g['n_pushed'][s])]+p[:12].tolist())
 rows=np.array(rows)[g['status']==0]
-names=['n_exp','n_push','iter','jh','jv','scan_it','compact','cyc_load','cyc_pop','cyc_closed','cyc_jump','cyc_push','cyc_walk','cyc_total']
+names=['n_exp','n_push','iter','taken','jobs','passes','scan_it','cyc_pop','cyc_closed','cyc_cand','cyc_jump','cyc_push','cyc_walk','cyc_total']
 print(names, '(cycles/16)')
 idx=np.argsort(-rows[:,13])[:6]
 for i in idx: print(rows[i].tolist())

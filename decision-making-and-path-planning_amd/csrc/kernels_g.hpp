@@ -5,10 +5,10 @@
 //                 rows): footprints are OR-ed into an LDS bit band, then the band is expanded to
 //                 bytes and written with 16-B-per-lane coalesced stores (HBM-write bound).
 //   k_search    : jump-point A*.  ONE WAVE per scene: the u8 grid is read once with 16-B-per-lane
-//                 coalesced loads and packed into an LDS obstacle bitmap; straight jumps are wave-wide
-//                 bit scans (32 cells per lane for E/W, one row per lane for N/S, ballot + ffs);
-//                 the open list is LDS resident (wave argmin pop, ballot + prefix-popcount
-//                 compaction); closed cells are a bit set in HBM.
+//                 coalesced loads into LDS obstacle bitmaps (row- and column-major); straight jumps
+//                 are lane-parallel bit scans (32 cells per lane, ballot + ffs), several per pass;
+//                 the open list and the closed-set hash are LDS resident (DPP minimum, ballot +
+//                 prefix-popcount compaction); up to 4 nodes of the minimal f are expanded per step.
 //   k_score     : lattice candidates (cubic Beziers to laterally shifted terminals + the grid
 //                 path) scored on collision / curvature / progress, 4 waves per scene.
 #pragma once
@@ -33,10 +33,9 @@ __device__ __forceinline__ int cell_of(const PlannerConfig& c, GlobalPoint2D ori
 }
 
 // ---------------------------------------------------------------------------------------
-// G1.  grid: [n_scenes][H][W] u8, 0 free / 1 occupied.  band_rows*W must be a multiple of 4096
-// bits... (host guarantees band_rows*W % 32 == 0 and W % 16 == 0).
+// G1.  grid: [n_scenes][H][W] u8, 0 free / 1 occupied (the host guarantees W % 32 == 0, so a band of
+// whole rows is a whole number of 32-bit words and of 16-byte stores).
 constexpr int kRasterBlock = 256;
-constexpr int kRasterMaxObs = 1024;
 
 __global__ void __launch_bounds__(kRasterBlock)
 k_rasterise(PlannerConfig c, int n_scenes, int band_rows, const SceneIn* __restrict__ in,
@@ -116,7 +115,6 @@ k_rasterise(PlannerConfig c, int n_scenes, int band_rows, const SceneIn* __restr
 }
 
 // ---------------------------------------------------------------------------------------
-// G2.
 __device__ __forceinline__ int hfun(int x, int y, int gx, int gy)
 {
     int dx = abs(x - gx), dy = abs(y - gy);
@@ -129,15 +127,19 @@ __device__ __forceinline__ uint32_t pack_nz4(uint32_t x)   // 4 bytes -> 4 bits 
 }
 
 // G2: jump-point A* (specification: oracle/dmpp_grid_oracle.c).  ONE WAVE per scene.
-//   * the u8 grid is read once (16 B per lane, coalesced) and packed to an LDS bitmap of obstacles;
-//   * a straight jump is ONE wave-wide bit scan: for E/W every lane takes a 32-cell word of the row
-//     (2048 cells per instruction) and builds the stop mask  blocked | forced | goal  from the three
-//     rows with shifts; for N/S every lane takes one row (64 rows per pass); ballot + ffs finds the
-//     first stop.  Diagonal moves are single steps that go through the open list;
-//   * the open list lives in LDS in push order (f/2, cell|dir, run): pop = wave argmin on
-//     (f, latest push), dead slots are squeezed out with ballot + prefix-popcount compaction;
-//   * closed cells are a bit set in HBM (one returning atomicOr per pop) plus dir/run per closed cell
-//     for the path, which is a handful of runs rather than hundreds of single cells.
+//   * the u8 grid is read once (16 B per lane, coalesced), packed to an LDS bitmap of obstacles and
+//     transposed in registers into a column-major copy: E/W and N/S jumps are both line scans;
+//   * a straight jump is a JOB of jw lanes (16 / 32 / 64 by grid width): every lane takes a 32-cell word
+//     of the line and builds the stop mask  blocked | forced | goal  from the three neighbouring lines
+//     with two shifts; ballot + ffs find the first stop.  All jumps of a step (<= 8) share passes;
+//   * a step takes up to 4 open entries of the minimal f (their g is final, so the search stays
+//     optimal), closes them and expands them on 4 x 8 lanes (node x direction); diagonal moves are
+//     single steps that go through the open list;
+//   * the open list lives in LDS in push order (f/2, x|y|dir, run): minimum by DPP wave reduction, ties
+//     picked with ballots, dead slots squeezed out with ballot + prefix-popcount compaction;
+//   * closed cells: an LDS hash (atomicCAS insertion) answers while it has room, a bit set in HBM is kept
+//     complete behind it; direction + run length per closed cell go to HBM for the path, which is a
+//     handful of runs rather than hundreds of single cells.
 constexpr int kOpenCap = DMPP_OPEN_CAP;
 constexpr int kClosedTab = 2048, kClosedMax = 1536;     // LDS closed-set hash; beyond kClosedMax the HBM bit set answers
 
@@ -157,22 +159,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 template <bool GBM>
 struct Bits {
     const uint32_t* bm; int W, H, WW;
-    // word w of row r, all ones outside the grid
-    __device__ __forceinline__ uint32_t word(int r, int w) const
-    {
-        const bool ok = r >= 0 && r < H && w >= 0 && w < WW;
-        const uint32_t v = bm[ok ? r * WW + w : 0];
-        return ok ? v : 0xFFFFFFFFu;
-    }
-    // the three cells (x-1, x, x+1) of row r as bits 0..2; x is wave-uniform
-    __device__ __forceinline__ uint32_t row3(int r, int x) const
-    {
-        const int wx = x >> 5, bx = x & 31;
-        const uint32_t w = word(r, wx);
-        if (bx >= 1 && bx <= 30) return (w >> (bx - 1)) & 7u;
-        if (bx == 0) return (word(r, wx - 1) >> 31) | ((w & 3u) << 1);
-        return ((w >> 30) & 3u) | ((word(r, wx + 1) & 1u) << 2);
-    }
+
     __device__ __forceinline__ bool blk(int x, int y) const
     {
         if (x < 0 || y < 0 || x >= W || y >= H) return true;
@@ -222,39 +209,6 @@ __device__ __forceinline__ int line_run(const LineJob& J, int k, uint32_t w, uin
     const int np = (((J.pos >> 5) + J.sgn * k) << 5) + bit;
     return J.sgn > 0 ? np - J.pos : J.pos - np;
 }
-// Two jumps in one pass: lanes 0..31 scan job A, lanes 32..63 job B (32 words = 1024 cells each).
-__device__ __forceinline__ void wave_jump_pair(const LineJob& A, const LineJob& Bj, int lane, int& runA, int& runB)
-{
-    const bool hi = lane >= 32;
-    LineJob J;
-    J.base = hi ? Bj.base : A.base; J.LW = hi ? Bj.LW : A.LW; J.NL = hi ? Bj.NL : A.NL;
-    J.line = hi ? Bj.line : A.line; J.pos = hi ? Bj.pos : A.pos; J.sgn = hi ? Bj.sgn : A.sgn;
-    J.gline = hi ? Bj.gline : A.gline; J.gpos = hi ? Bj.gpos : A.gpos; J.active = hi ? Bj.active : A.active;
-    uint32_t B0 = 0, stop = 0;
-    if (J.active) stop = line_stop(J, lane & 31, B0);
-    const unsigned long long m = __ballot(stop != 0);
-    runA = 0; runB = 0;
-    const unsigned mA = (unsigned)m, mB = (unsigned)(m >> 32);
-    if (mA) {
-        const int L = __ffs((int)mA) - 1;
-        runA = line_run(A, L, (uint32_t)__builtin_amdgcn_readlane((int)stop, L), (uint32_t)__builtin_amdgcn_readlane((int)B0, L));
-    }
-    if (mB) {
-        const int L = __ffs((int)mB) - 1;
-        runB = line_run(Bj, L, (uint32_t)__builtin_amdgcn_readlane((int)stop, 32 + L), (uint32_t)__builtin_amdgcn_readlane((int)B0, 32 + L));
-    }
-}
-// One jump on the whole wave (64 words = 2048 cells): for views wider than 32 words.
-__device__ __forceinline__ int wave_jump_one(const LineJob& J, int lane)
-{
-    uint32_t B0 = 0;
-    const uint32_t stop = line_stop(J, lane, B0);
-    const unsigned long long m = __ballot(stop != 0);
-    if (m == 0) return 0;
-    const int L = __ffsll((long long)m) - 1;
-    return line_run(J, L, (uint32_t)__builtin_amdgcn_readlane((int)stop, L), (uint32_t)__builtin_amdgcn_readlane((int)B0, L));
-}
-
 // Bit-matrix transpose of the row-major bitmap (H lines x WW words) into the column-major one
 // (W lines x HW words), 32x32 blocks in registers: each lane takes blocks lane, lane+64, ...
 __device__ __forceinline__ void transpose_bits(const uint32_t* src, uint32_t* dst, int W, int H, int lane)

@@ -344,3 +344,37 @@ def test_grid_1024_lds_optin(dm, oracle):
     sc = dm.gen_scenes(cfg, 22000, 6, 64, junction_every=0)
     pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=1)
     _assert_tick(res[0], "1024")
+
+
+def test_edge_cases(dm, oracle):
+    """Long obstacle lists (read from HBM, not staged in LDS), ID_MORE, wide lanes (more sweep
+    candidates), short / empty refpaths and lanes, an ego at the very end of its lane."""
+    cfg = dm.default_config(512)
+    cfg["ID_MORE"] = 3
+    sc = dm.gen_scenes(cfg, 31000, 24, 600, junction_every=4)          # 600 > 512 obstacles per scene
+    si = sc["scene_in"]
+    si["lanes"]["lane_width"][::3] = 7.0                               # (7.0 - 1.8) / 0.6 -> 9 candidates, capped at 8
+    si["lanes"]["lanechg_attribute"][::3] = 0
+    si["ref_n"][1], si["dec"]["refpath_n"][1] = 2, 2                   # fewer than 3 refpath points (Planning.cpp:507 fence)
+    si["ref_n"][2], si["dec"]["refpath_n"][2] = 0, 0
+    si["loc"]["id"][3] = dm.GEN_LANE_PTS - 2                           # two points left on the lane
+    si["loc"]["id"][4] = dm.GEN_LANE_PTS + 5                           # id past the end (Decision.cpp:581 min())
+    si["lanes"]["cur_n"][5] = 1
+    si["lanes"]["left_n"][6] = 0
+    si["obs_n"][7] = 0                                                 # no obstacle at all
+    for stage in (1, 0):
+        cfg["decision_stage"] = stage
+        pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=4, mutate=lambda sc, t: None)
+        for t, r in enumerate(res):
+            _assert_tick(r, f"stage {stage} tick {t}")
+
+
+def test_zero_and_one_scene(dm, oracle):
+    cfg = dm.default_config(128)
+    pl = dm.Planner(cfg, max_scenes=2, max_obs_total=16)
+    pl.tick(sync=True)                                                  # nothing resident: a no-op
+    sc = dm.gen_scenes(cfg, 77, 1, 8, junction_every=0)
+    st_g, st_o = sc["state"].copy(), sc["state"].copy()
+    plan_g, gout_g = pl.plan_tick_batch(sc, st_g)
+    plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st_o)
+    assert not (compare(plan_g, plan_o) + compare(st_g, st_o) + compare(gout_g, gout_o))

@@ -15,7 +15,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
 pre = lambda kind: os.path.join(src, f"prof_{tag}_{kind}") if os.path.isdir(os.path.join(src, f"prof_{tag}_{kind}")) else os.path.join(src, f"prof_{kind}")
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(os.path.join(pre("stats"), "*", "*_kernel_stats.csv"))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # gpurun merges runs into one directory
+stats = newest(os.path.join(pre("stats"), "*", "*_kernel_stats.csv"))
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 out = {"units": "bytes per launch; FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KiB", "kernels": {}}
 for r in csv.DictReader(open(stats)):
@@ -23,7 +24,7 @@ for r in csv.DictReader(open(stats)):
     out["kernels"].setdefault(name, {})["avg_ns"] = float(r["AverageNs"])
     out["kernels"][name]["calls"] = int(r["Calls"])
 for kind, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = glob.glob(os.path.join(pre(kind), "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(pre(kind), "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != key:

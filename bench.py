@@ -83,7 +83,6 @@ def main():
     pl = dm.Planner(cfg, device=local_rank, max_scenes=n, max_obs_total=max(n * n_obs, 1))
 
     # ---- inputs: generated on rank 0, scattered over RCCL, handed to the library as device pointers ----
-    keys = ["scene_in", "lane_pool", "ref_pool", "obs_pool", "mot_pool", "state"]
     if world == 1:
         sc = dm.gen_scenes(cfg, 0, n, n_obs, junction_every=8)
         pl.set_scenes(sc)
@@ -93,7 +92,8 @@ def main():
         recv = sharding.scatter_scenes(dm, dist, torch, cfg, n, n_obs, rank, world, torch.device('cuda', local_rank))
         torch.cuda.synchronize()
         lib = pl.lib
-        dm._check(lib.pp_set_scenes(pl.h, n, recv["scene_in"].data_ptr(), recv["lane_pool"].data_ptr(), n * 3 * dm.GEN_LANE_PTS,
+        dm._check(lib.pp_set_scenes(pl.h, n, recv["scene_in"].data_ptr(), recv["lane_pool"].data_ptr(), recv["attr_pool"].data_ptr(),
+                                    n * 3 * dm.GEN_LANE_PTS,
                                     recv["ref_pool"].data_ptr(), n * dm.GEN_REF_PTS, recv["obs_pool"].data_ptr(),
                                     recv["mot_pool"].data_ptr(), n * n_obs))
         dm._check(lib.pp_set_state(pl.h, recv["state"].data_ptr(), n))

@@ -28,7 +28,7 @@ def _dt(fields):
     return np.dtype(fields, align=True)
 
 
-f8, i4, u4, f4, u8 = np.float64, np.int32, np.uint32, np.float32, np.uint64
+f8, i4, u4, f4, u8, u2 = np.float64, np.int32, np.uint32, np.float32, np.uint64, np.uint16
 GlobalPoint2D = _dt([("x", f8), ("y", f8)])
 GlobalPoint3D = _dt([("x", f8), ("y", f8), ("dir", f8)])
 AimPoint = _dt([("Aim_point", GlobalPoint3D), ("Aim_id", i4), ("_pad", i4)])
@@ -56,9 +56,10 @@ SceneState = _dt([("last_Bpoints", GlobalPoint2D, (PATH_POINTS,)), ("aimpoint_fa
                   ("z_behavior_to_dlg", i4), ("z_segment_lanechg_status", i4), ("z_segment_obsavoid_status", i4),
                   ("d_his_behavior", i4), ("d_his_light_status", i4), ("d_his_target_lanenum", i4),
                   ("obsavoid_time", u4), ("no_obsaviod_time", u4), ("frontobs_time", u4), ("tick", i4), ("_pad", i4),
-                  ("z_velocity_expect", f8)])
+                  ("z_velocity_expect", f8), ("leftlight_time", f8), ("rightlight_time", f8)])
 SceneIn = _dt([("loc", LocationOut), ("dec", DecisionOut), ("lanes", LaneView), ("ref_off", i4), ("ref_n", i4),
-               ("obs_off", i4), ("obs_n", i4), ("stub_attribute", i4), ("_pad", i4), ("grid_origin", GlobalPoint2D),
+               ("obs_off", i4), ("obs_n", i4), ("stub_attribute", i4), ("_pad", i4), ("out_lane_no", u2, (LANESUM,)),
+               ("period_last", f8), ("grid_origin", GlobalPoint2D),
                ("goal", GlobalPoint2D)])
 GridOut = _dt([("order_digest", u8), ("status", i4), ("n_expanded", i4), ("n_pushed", i4), ("n_rounds", i4),
                ("path_len", i4), ("path_cost", i4), ("start_cell", i4), ("goal_cell", i4), ("best_candidate", i4),
@@ -67,14 +68,15 @@ GridOut = _dt([("order_digest", u8), ("status", i4), ("n_expanded", i4), ("n_pus
                ("best_path", GlobalPoint2D, (PATH_POINTS,))])
 PlanOut = _dt([("result", PlanningOut), ("show", PlanningStatus), ("road_points", GlobalPoint2D, (PATH_POINTS,)),
                ("around", Path_Obs, (6,)), ("dec", DecisionOut), ("ob_dis_lat", f8), ("ob_dis_lng", f8), ("ob", ObPoint),
-               ("ob_flag", i4), ("ob_pathid", i4), ("sweep_side", i4), ("sweep_index", i4), ("_pad", i4, (2,))])
+               ("ob_flag", i4), ("ob_pathid", i4), ("sweep_side", i4), ("sweep_index", i4), ("navi_lanechg", i4),
+               ("navi_lanechg_times", i4)])
 PlannerConfig = _dt([("ROAD_FARAIM_MAX", f8), ("ROAD_FARAIM_MIN", f8), ("PRE_INTER_FARAIM", f8), ("INTER_FARAIM", f8),
                      ("ROAD_REMAIN_DISTANCE", f8), ("INTER_REMAIN_DISTANCE", f8), ("EPSILON", f8), ("PI", f8),
                      ("Vehicle_Width", f8), ("NO_OBSTACLE_DIS", f8), ("wgs_lat0", f8), ("wgs_lng0", f8),
                      ("wgs_deg_per_m_lat", f8), ("wgs_deg_per_m_lng", f8), ("ID_MORE", i4), ("decision_stage", i4),
-                     ("grid_stage", i4), ("grid_w", i4), ("grid_h", i4), ("max_expansions", i4), ("bucket_cap", i4),
+                     ("lanechg_stage", i4), ("grid_stage", i4), ("grid_w", i4), ("grid_h", i4), ("max_expansions", i4), ("bucket_cap", i4),
                      ("max_path", i4), ("n_lattice", i4), ("lookahead_cells", i4), ("dynamic_obstacles", i4),
-                     ("force_replan", i4), ("cell", f8), ("inflate", f8), ("lattice_step", f8), ("d_safe", f8),
+                     ("force_replan", i4), ("_cfg_pad", i4), ("cell", f8), ("inflate", f8), ("lattice_step", f8), ("d_safe", f8),
                      ("w_col", f8), ("w_curv", f8), ("w_prog", f8), ("w_off", f8), ("dyn_dt", f8)])
 PlannerCaps = _dt([("max_scenes", i4), ("max_obs_total", i4), ("max_lane_pts_total", i4), ("max_ref_pts_total", i4),
                    ("order_cap", i4), ("_pad", i4)])
@@ -112,11 +114,11 @@ def load_library(path=None):
     lib.pp_default_config.restype = None
     lib.pp_init_state.argtypes = [vp, ci]
     lib.pp_init_state.restype = None
-    lib.pp_gen_scenes.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+    lib.pp_gen_scenes.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.pp_create.argtypes = [vp, ci, vp, C.POINTER(vp)]
     lib.pp_destroy.argtypes = [vp]
     lib.pp_set_config.argtypes = [vp, vp]
-    lib.pp_set_scenes.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, vp, ci]
+    lib.pp_set_scenes.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, vp, ci]
     lib.pp_set_n_scenes.argtypes = [vp, ci]
     lib.pp_set_state.argtypes = [vp, vp, ci]
     lib.pp_plan_tick.argtypes = [vp]
@@ -128,7 +130,7 @@ def load_library(path=None):
     lib.pp_get_order.argtypes = [vp, ci, vp, ci]
     lib.pp_get_path.argtypes = [vp, ci, vp, ci]
     lib.pp_get_refpath.argtypes = [vp, ci, vp, ci]
-    lib.pp_plan_tick_batch.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp]
+    lib.pp_plan_tick_batch.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, ci, vp, vp, vp]
     lib.pp_search_obstacle_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.pp_geom_batch.argtypes = [vp, ci, ci, vp, vp, vp, vp]
     lib.pp_scalar_stage.argtypes = [vp, ci, vp, ci, vp, vp, ci]
@@ -176,14 +178,15 @@ def gen_scenes(cfg, first_scene, n_scenes, n_obs, junction_every=8):
     sc = dict(
         scene_in=np.zeros(n_scenes, SceneIn),
         lane_pool=np.zeros(n_scenes * 3 * GEN_LANE_PTS, GlobalPoint3D),
+        attr_pool=np.zeros(n_scenes * 3 * GEN_LANE_PTS, np.uint8),
         ref_pool=np.zeros(n_scenes * GEN_REF_PTS, GlobalPoint2D),
         obs_pool=np.zeros(max(n_scenes * n_obs, 1), ObPoint),
         mot_pool=np.zeros(max(n_scenes * n_obs, 1), ObMotion),
         state=np.zeros(n_scenes, SceneState),
     )
     _check(lib.pp_gen_scenes(_ptr(cfg), first_scene, n_scenes, n_obs, junction_every, _ptr(sc["scene_in"]),
-                             _ptr(sc["lane_pool"]), _ptr(sc["ref_pool"]), _ptr(sc["obs_pool"]), _ptr(sc["mot_pool"]),
-                             _ptr(sc["state"])))
+                             _ptr(sc["lane_pool"]), _ptr(sc["attr_pool"]), _ptr(sc["ref_pool"]), _ptr(sc["obs_pool"]),
+                             _ptr(sc["mot_pool"]), _ptr(sc["state"])))
     sc["n_obs"] = n_obs
     return sc
 
@@ -220,7 +223,8 @@ class Planner:
 
     def set_scenes(self, sc, with_motion=True):
         n = len(sc["scene_in"])
-        _check(self.lib.pp_set_scenes(self.h, n, _ptr(sc["scene_in"]), _ptr(sc["lane_pool"]), len(sc["lane_pool"]),
+        _check(self.lib.pp_set_scenes(self.h, n, _ptr(sc["scene_in"]), _ptr(sc["lane_pool"]), _ptr(sc.get("attr_pool")),
+                                      len(sc["lane_pool"]),
                                       _ptr(sc["ref_pool"]), len(sc["ref_pool"]), _ptr(sc["obs_pool"]),
                                       _ptr(sc["mot_pool"]) if with_motion else None, n * sc["n_obs"]))
         self.n = n
@@ -279,7 +283,8 @@ class Planner:
         gout = np.zeros(n, GridOut) if want_grid else None
         _check(self.lib.pp_plan_tick_batch(self.h, n, _ptr(sc["scene_in"]), _ptr(sc["obs_pool"]),
                                            _ptr(sc["mot_pool"]) if with_motion else None, n * sc["n_obs"],
-                                           _ptr(sc["lane_pool"]), len(sc["lane_pool"]), _ptr(sc["ref_pool"]),
+                                           _ptr(sc["lane_pool"]), _ptr(sc.get("attr_pool")), len(sc["lane_pool"]),
+                                           _ptr(sc["ref_pool"]),
                                            len(sc["ref_pool"]), _ptr(state), _ptr(plan), _ptr(gout)))
         self.n = n
         return plan, gout

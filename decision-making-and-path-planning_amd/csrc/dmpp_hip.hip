@@ -36,7 +36,7 @@ struct pp_planner {
     int n_scenes = 0;
     hipStream_t stream = nullptr;
     // inputs
-    SceneIn* d_in = nullptr; GlobalPoint3D* d_lane = nullptr; GlobalPoint2D* d_ref = nullptr;
+    SceneIn* d_in = nullptr; GlobalPoint3D* d_lane = nullptr; uint8_t* d_attr = nullptr; bool have_attr = false; GlobalPoint2D* d_ref = nullptr;
     ObPoint* d_obs = nullptr; ObMotion* d_mot = nullptr; ObPoint* d_obs_now = nullptr;
     bool have_motion = false;
     // state / outputs
@@ -168,6 +168,7 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     const size_t ns = (size_t)caps->max_scenes;
     if ((r = dmalloc(&h->d_in, ns))) return bail(r);
     if ((r = dmalloc(&h->d_lane, (size_t)caps->max_lane_pts_total))) return bail(r);
+    if ((r = dmalloc(&h->d_attr, (size_t)caps->max_lane_pts_total + 1))) return bail(r);
     if ((r = dmalloc(&h->d_ref, (size_t)caps->max_ref_pts_total))) return bail(r);
     if ((r = dmalloc(&h->d_obs, (size_t)caps->max_obs_total))) return bail(r);
     if ((r = dmalloc(&h->d_mot, (size_t)caps->max_obs_total))) return bail(r);
@@ -201,7 +202,7 @@ int pp_destroy(pp_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
-    void* bufs[] = { h->d_in, h->d_lane, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now, h->d_state, h->d_plan, h->d_gout,
+    void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now, h->d_state, h->d_plan, h->d_gout,
                      h->d_dec_ref, h->d_grid, h->d_pinfo, h->d_closed, h->d_order, h->d_path, h->d_gbm, h->d_scratch };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -223,8 +224,8 @@ int pp_set_config(pp_handle h, const PlannerConfig* cfg)
     return setup_grid_launch(h);
 }
 
-int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoint3D* lane_pool, int n_lane_pts,
-                  const GlobalPoint2D* ref_pool, int n_ref_pts, const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total)
+int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoint3D* lane_pool, const uint8_t* lane_attr_pool,
+                  int n_lane_pts, const GlobalPoint2D* ref_pool, int n_ref_pts, const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total)
 {
     if (!h || !in) return fail(PP_ERR_ARG, "null argument");
     if (n_scenes < 0 || n_scenes > h->caps.max_scenes) return fail(PP_ERR_CAPACITY, "n_scenes exceeds caps.max_scenes");
@@ -234,6 +235,11 @@ int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoin
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(h->d_in, in, (size_t)n_scenes * sizeof(SceneIn), hipMemcpyDefault, h->stream));
     if (n_lane_pts && lane_pool) HIP_TRY(hipMemcpyAsync(h->d_lane, lane_pool, (size_t)n_lane_pts * sizeof(GlobalPoint3D), hipMemcpyDefault, h->stream));
+    h->have_attr = false;
+    if (n_lane_pts && lane_attr_pool) {
+        HIP_TRY(hipMemcpyAsync(h->d_attr, lane_attr_pool, (size_t)n_lane_pts, hipMemcpyDefault, h->stream));
+        h->have_attr = true;
+    }
     if (n_ref_pts && ref_pool) HIP_TRY(hipMemcpyAsync(h->d_ref, ref_pool, (size_t)n_ref_pts * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
     if (n_obs_total && obs_pool) HIP_TRY(hipMemcpyAsync(h->d_obs, obs_pool, (size_t)n_obs_total * sizeof(ObPoint), hipMemcpyDefault, h->stream));
     h->have_motion = false;
@@ -271,6 +277,8 @@ int pp_plan_tick(pp_handle h)
     if (n <= 0) return PP_OK;
     HIP_TRY(hipSetDevice(h->device));
     const PlannerConfig& c = h->cfg;
+    if (c.decision_stage && c.lanechg_stage && !h->have_attr)
+        return fail(PP_ERR_ARG, "cfg.lanechg_stage needs the lane attribute pool (pp_set_scenes lane_attr_pool)");
     {
         Timed t(h, PP_K_OBSTACLES);
         hipLaunchKernelGGL(dmpp::k_effective_obstacles, dim3(n), dim3(dmpp::kBlock), 0, h->stream, c, n, h->d_in, h->d_state,
@@ -279,7 +287,7 @@ int pp_plan_tick(pp_handle h)
     if (c.decision_stage) {
         Timed t(h, PP_K_DECISION);
         hipLaunchKernelGGL(dmpp::k_decision, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::DecShared), h->stream, c, n, h->d_in, h->d_lane,
-                           h->d_ref, h->d_obs_now, h->d_state, h->d_plan, h->d_dec_ref);
+                           h->d_attr, h->d_ref, h->d_obs_now, h->d_state, h->d_plan, h->d_dec_ref);
     }
     {
         Timed t(h, PP_K_PLANNING);
@@ -378,12 +386,12 @@ int pp_get_path(pp_handle h, int scene, int32_t* path, int cap)
 }
 
 int pp_plan_tick_batch(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total,
-                       const GlobalPoint3D* lane_pool, int n_lane_pts, const GlobalPoint2D* ref_pool, int n_ref_pts,
-                       SceneState* state_inout, PlanOut* out, GridOut* grid_out)
+                       const GlobalPoint3D* lane_pool, const uint8_t* lane_attr_pool, int n_lane_pts,
+                       const GlobalPoint2D* ref_pool, int n_ref_pts, SceneState* state_inout, PlanOut* out, GridOut* grid_out)
 {
     if (!h || !state_inout || !out) return fail(PP_ERR_ARG, "null argument");
     int r;
-    if ((r = pp_set_scenes(h, n_scenes, in, lane_pool, n_lane_pts, ref_pool, n_ref_pts, obs_pool, mot_pool, n_obs_total))) return r;
+    if ((r = pp_set_scenes(h, n_scenes, in, lane_pool, lane_attr_pool, n_lane_pts, ref_pool, n_ref_pts, obs_pool, mot_pool, n_obs_total))) return r;
     if ((r = pp_set_state(h, state_inout, n_scenes))) return r;
     if ((r = pp_plan_tick(h))) return r;
     if ((r = pp_get_plan(h, out, n_scenes))) return r;
@@ -636,6 +644,7 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes)
     case PP_BUF_GRID_OUT: p = h->d_gout; b = ns * sizeof(GridOut); break;
     case PP_BUF_GRID: p = h->d_grid; b = ns * h->grid_cells; break;
     case PP_BUF_PATH: p = h->d_path; b = ns * (size_t)h->max_path0 * 4; break;
+    case PP_BUF_LANE_ATTR: p = h->d_attr; b = (size_t)h->caps.max_lane_pts_total; break;
     case PP_BUF_ORDER: p = h->d_order; b = ns * (size_t)h->caps.order_cap * 4; break;
     default: break;
     }

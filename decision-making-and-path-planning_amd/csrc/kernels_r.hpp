@@ -126,6 +126,7 @@ struct DecShared {
     double sweep_lng[2 * DMPP_MAX_SWEEP];
     int n[6];
     int n_ref, do_sweep, n_cand;
+    int rem_go, rem_flags;                        // remaining lane-change length tests (lane-change rule tree)
 };
 
 __device__ inline int dev_load_front(const PlannerConfig& c, const GlobalPoint3D* lane, int IdSum, int Id, GlobalPoint2D* out)
@@ -158,9 +159,130 @@ __device__ inline void store_path_obs(Path_Obs* dst, const SoResult& r, const Ob
     *dst = p;
 }
 
+// ---------------------------------------------------------------------------------------
+// Lane-change rule tree of CDecision::BehaviorDecision, Decision.cpp:1017-1772, run by one thread per scene
+// on the corridor distances k_decision has just produced.  `rem` holds the remaining-length tests (see
+// k_decision).  The tree's leaves come in three shapes, named here:
+//   go(b, t)  : start the lane change          (behavior b, target lane t, lanechg_status 1)
+//   keep()    : stay, lanechg_status cleared   (behavior 1, target = current lane, lanechg_status 0)
+//   keep_ns() : stay, lanechg_status untouched (the branches of :1623-1634, :1667-1685, :1717-1728)
+// Oddities of the reference text are kept and marked "as written".
+__device__ inline void lane_change_tree(const SceneIn& si, int LaneNum_Cur, int LaneSum, int Map, unsigned navi, int rem,
+                                        double F, double LF, double LR, double RF, double RR,
+                                        SceneState& st, Behavior_Dec& Cur)
+{
+    const double period = si.period_last;
+    double left_t = st.leftlight_time, right_t = st.rightlight_time;
+    unsigned frontobs = st.frontobs_time;
+    auto go = [&](int b, int t) { Cur.behavior = b; Cur.target_lanenum = t; Cur.lanechg_status = 1; };
+    auto keep = [&]() { Cur.behavior = 1; Cur.target_lanenum = LaneNum_Cur; Cur.lanechg_status = 0; };
+    auto keep_ns = [&]() { Cur.behavior = 1; Cur.target_lanenum = LaneNum_Cur; };
+    auto exits_via = [&](int lane_no) {           // is lane_no one of the navigation's exit lanes (:1166-1172)
+        bool hit = false;
+        for (int i = 0; i < DMPP_LANESUM && si.out_lane_no[i] != 0; i++) hit = hit || ((int)si.out_lane_no[i] == lane_no);
+        return hit;
+    };
+    // signal bookkeeping shared by the obstacle-triggered branches: restart the timer when `restart`, add the period, cap
+    auto run_left_timer = [&](bool restart, double cap_to) {
+        if (restart) left_t = 0;
+        left_t += period;
+        if (left_t > 2000) left_t = cap_to;
+    };
+    const bool A60 = rem & 1, B10 = rem & 2, B15 = rem & 4, B50 = rem & 8;
+
+    if (Cur.lanechg_status == 0) {
+        if (navi == 1) {                                                       // :1024 navigation wants the left lane
+            if (Map == 1 || Map == 3) {
+                Cur.behavior_to_dlg = 2;
+                if (Cur.light_status != 1) { Cur.light_status = 1; left_t = 0; }
+                left_t += period;
+                if ((LF > F + 10 || LF > 40) && LR > 15 && left_t > 2000) go(2, LaneNum_Cur - 1); else keep();
+            } else { keep(); Cur.behavior_to_dlg = 4; }
+        } else if (navi == 2) {                                                // :1086 navigation wants the right lane
+            if (Map == 2 || Map == 3) {
+                Cur.behavior_to_dlg = 3;
+                if (Cur.light_status != 2) { Cur.lanechg_status = 2; right_t = 0; }   // :1094 as written (status, not light)
+                right_t += period;
+                if ((RF > F + 10 || RF > 40) && RR > 15 && right_t >= 2000) go(3, LaneNum_Cur + 1); else keep();
+            } else { keep(); Cur.behavior_to_dlg = 4; }
+        } else if (navi == 0) {                                                // :1146 no navigation demand
+            if (F < 25) {                                                      // :1149
+                frontobs++;
+                if (frontobs > 2) {
+                    frontobs = 3;
+                    if (Map == 1) {                                            // :1157
+                        if (LaneNum_Cur > 1) {
+                            Cur.behavior_to_dlg = 5;
+                            bool chg;
+                            if (!exits_via(LaneNum_Cur - 1)) {                 // must come back: needs 60 m of attribute-1 lane
+                                chg = A60;
+                                // :1193-1206 test and set the member z_light_status, which :308 then overwrites with
+                                // Cur.light_status: only the timer restart survives
+                                if (chg) run_left_timer(Cur.light_status != 1, 2000);
+                            } else {
+                                chg = B15;
+                                if (chg) { const bool r = Cur.light_status != 1; Cur.light_status = 1; run_left_timer(r, 2100); }  // :1232 as written
+                                else Cur.light_status = 0;
+                            }
+                            if (chg && LF > F + 10 && LR > 10 && left_t > 1500) { frontobs = 0; go(2, LaneNum_Cur - 1); } else keep();
+                        } else keep();
+                    } else if (Map == 2) {                                     // :1296
+                        if (LaneNum_Cur < LaneSum) {
+                            Cur.behavior_to_dlg = 6;
+                            bool chg;
+                            if (!exits_via(LaneNum_Cur - 1)) {                 // :1307 as written (the left neighbour)
+                                chg = B50;
+                                if (chg) { const bool r = Cur.light_status != 2; Cur.light_status = 2; run_left_timer(r, 2000); }
+                            } else {
+                                chg = B10;
+                                if (chg) { const bool r = Cur.light_status != 1; Cur.light_status = 1; run_left_timer(r, 2000); }  // :1356 as written
+                            }
+                            if (chg && RF > F + 10 && RR > 10 && left_t > 1500) { frontobs = 0; go(3, LaneNum_Cur + 1); } else keep();
+                        } else keep();
+                    } else if (Map == 3) {                                     // :1426
+                        const bool back_l = !exits_via(LaneNum_Cur - 1), back_r = !exits_via(LaneNum_Cur + 1);
+                        // :1477 parses to a constant-false predicate: a left change that need not come back never qualifies
+                        const bool left_ok = (LaneNum_Cur > 1) && back_l && B50;
+                        const bool right_ok = (LaneNum_Cur < LaneSum) && (back_r ? B50 : B10);
+                        if (left_ok && !back_l) {                              // :1545 (unreachable given the line above; kept)
+                            const bool r = Cur.lanechg_status != 1;
+                            if (r) Cur.light_status = 1;
+                            run_left_timer(r, 2000);
+                            if (LF > F + 10 && LR > 10 && left_t > 2000) { frontobs = 0; go(2, LaneNum_Cur - 1); } else keep();
+                        } else if (right_ok && !back_r) {                      // :1596
+                            const bool r = Cur.light_status != 2; Cur.light_status = 2;
+                            run_left_timer(r, 2000);
+                            if (RF > F + 10) {                                 // no else in the reference
+                                if (RR > 10 && left_t > 2000) { frontobs = 0; go(3, LaneNum_Cur + 1); } else keep_ns();
+                            }
+                        } else if (left_ok) {                                  // :1638
+                            const bool r = Cur.light_status != 1;
+                            if (r) Cur.lanechg_status = 1;                     // :1642 as written (status, not light)
+                            run_left_timer(r, 2000);
+                            if (LF > F + 10 && LR > 10 && left_t > 2000) { frontobs = 0; go(2, LaneNum_Cur - 1); } else keep_ns();
+                        } else if (right_ok) {                                 // :1688
+                            const bool r = Cur.light_status != 2; Cur.light_status = 2;
+                            run_left_timer(r, 2000);
+                            if (RF > F + 10) {                                 // no else in the reference
+                                if (RR > 10 && left_t > 2000) { frontobs = 0; go(3, 1); }   // :1712 as written: target lane 1
+                                else keep_ns();
+                            }
+                        } else keep();
+                    }
+                } else keep();                                                 // :1741-1746
+            } else { frontobs = 0; Cur.behavior_to_dlg = 8; keep(); }          // :1749-1756
+        }
+    } else if (Cur.lanechg_status == 1) {                                      // :1760 changing lanes
+        Cur.behavior_to_dlg = 9;
+        if (Cur.target_lanenum == LaneNum_Cur) Cur.lanechg_status = 0;         // (the light reset of :1766 is overwritten at :1770)
+        Cur.behavior = st.d_his_behavior; Cur.target_lanenum = st.d_his_target_lanenum; Cur.light_status = st.d_his_light_status;
+    }
+    st.leftlight_time = left_t; st.rightlight_time = right_t; st.frontobs_time = frontobs;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const GlobalPoint3D* __restrict__ lane_pool,
-           const GlobalPoint2D* __restrict__ ref_pool, const ObPoint* __restrict__ obs_now,
+           const uint8_t* __restrict__ attr_pool, const GlobalPoint2D* __restrict__ ref_pool, const ObPoint* __restrict__ obs_now,
            SceneState* __restrict__ state, PlanOut* __restrict__ plan, GlobalPoint2D* __restrict__ dec_ref)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -256,7 +378,76 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
             }
         }
         __syncthreads();
+        // ---- lane-change rule tree, part 1: the "remaining lane-change length" tests ----
+        // Decision.cpp:1178-1187 (and :1212, 1316, 1344, 1459, 1477, 1506, 1523) walk the current lane from the ego point
+        // while the next point's lanechg_attribute passes a predicate, summing segment lengths, and compare the sum with
+        // 60 / 50 / 15 / 10 m.  As the compiler parses them the predicates are `attr == 1` (A), `attr & 1` (B) and
+        // constant false.  Partial sums of non-negative lengths never decrease, so "sum > t" is "some partial sum > t":
+        // segment lengths are produced 256 at a time by the block, thread 0 adds them in order and stops early.
+        //   rem_flags bit0: A > 60, bit1: B > 10, bit2: B > 15, bit3: B > 50
+        const bool run_tree = (LaneChg != 0) && c.lanechg_stage;
+        if (run_tree) {
+            double* seg = reinterpret_cast<double*>(sh.ref);
+            unsigned char* sa = reinterpret_cast<unsigned char*>(seg + kBlock);
+            const uint8_t* attr = attr_pool + si.lanes.cur_off;
+            const int IdSum = si.lanes.cur_n;
+            int base = max(Id_Cur, 0);
+            double sumA = 0, sumB = 0; bool liveA = true, liveB = true; int flags = 0;
+            if (tid == 0) { sh.rem_go = 1; sh.rem_flags = 0; }
+            for (;;) {
+                __syncthreads();
+                if (!sh.rem_go) break;
+                const int i = base + tid;
+                if (i < IdSum - 1) {
+                    GlobalPoint2D a = { cur[i].x, cur[i].y }, b = { cur[i + 1].x, cur[i + 1].y };
+                    seg[tid] = CalcDistance(a, b); sa[tid] = attr[i + 1];
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    const int cnt = min(kBlock, IdSum - 1 - base);
+                    for (int k = 0; k < cnt && (liveA || liveB); k++) {
+                        const unsigned a = sa[k]; const double d = seg[k];
+                        if (liveA) { if (a == 1) { sumA += d; if (sumA > 60) { flags |= 1; liveA = false; } } else liveA = false; }
+                        if (liveB) {
+                            if (a & 1) {
+                                sumB += d;
+                                if (sumB > 10) flags |= 2;
+                                if (sumB > 15) flags |= 4;
+                                if (sumB > 50) { flags |= 8; liveB = false; }
+                            } else liveB = false;
+                        }
+                    }
+                    if (cnt < kBlock) { liveA = false; liveB = false; }
+                    sh.rem_go = (liveA || liveB) ? 1 : 0;
+                    sh.rem_flags = flags;
+                }
+                base += kBlock;
+            }
+        }
         if (tid == 0) {
+            // Nav_LaneChange, Decision.cpp:685-738 (+ CalcNaviLaneChgTimes :498-538)
+            unsigned navi = 4, navi_times = 0;
+            {
+                const unsigned L = (unsigned)LaneNum_Cur;
+                for (int i = 0; i < DMPP_LANESUM && si.out_lane_no[i] != 0; i++) if (L == si.out_lane_no[i]) { navi = 0; break; }
+                const unsigned lane_min = si.out_lane_no[0];
+                unsigned lane_max = 1;
+                for (int i = 0; i < DMPP_LANESUM; i++) lane_max = max(lane_max, (unsigned)si.out_lane_no[i]);
+                if (navi == 4) {
+                    const int dir = (L < lane_min) ? 2 : (L > lane_max) ? 1 : 0;
+                    navi = (unsigned)dir;
+                    if (dir) {
+                        int times = 5;
+                        const int lc = (int)(L & 0xffu);
+                        for (int i = 0; i < DMPP_LANESUM && si.out_lane_no[i] != 0; i++) {
+                            const int t = (dir == 1) ? lc - (int)si.out_lane_no[i] : (int)si.out_lane_no[i] - lc;
+                            times = min(times, t);
+                        }
+                        navi_times = (unsigned)(times & 0xff);
+                    }
+                }
+            }
+            po.navi_lanechg = (int)navi; po.navi_lanechg_times = (int)navi_times;
             Behavior_Dec Cur;
             Cur.behavior = st.z_behavior; Cur.light_status = st.z_light_status; Cur.target_lanenum = st.z_target_lanenum;
             Cur.lanechg_status = st.z_segment_lanechg_status; Cur.obsavoid_status = st.z_segment_obsavoid_status;
@@ -295,6 +486,10 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
                 }
             } else {
                 st.no_obsaviod_time = 0; st.obsavoid_time = 0;      // Decision.cpp:1014-1015
+                if (run_tree)
+                    lane_change_tree(si, LaneNum_Cur, LaneSum, LaneChg, navi, sh.rem_flags,
+                                     F_lng, (nLF != 0) ? sh.around[2].dis_lng : 0.0, (nLR != 0) ? sh.around[3].dis_lng : 0.0,
+                                     (nRF != 0) ? sh.around[4].dis_lng : 0.0, (nRR != 0) ? sh.around[5].dis_lng : 0.0, st, Cur);
             }
             st.z_velocity_expect = (Cur.behavior == 4 || Cur.behavior == 5) ? 5 : 10;   // SpeedDecision
             st.z_behavior = Cur.behavior; st.z_light_status = Cur.light_status; st.z_target_lanenum = Cur.target_lanenum;
@@ -346,14 +541,14 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
             else { st.z_velocity_expect = 10; st.z_behavior_to_dlg = 1; }
             st.z_light_status = (si.stub_attribute == 3) ? 1 : si.stub_attribute;
             st.z_behavior = 1; st.z_target_roadnum = loc.road_num; st.z_target_lanenum = loc.lane_num;
-            po.sweep_side = 0; po.sweep_index = -1;
+            po.sweep_side = 0; po.sweep_index = -1; po.navi_lanechg = 0; po.navi_lanechg_times = 0;
             sh.n_ref = n;
         }
         for (int i = tid; i < n; i += kBlock) out_ref[i] = sh.ref[i];
         __syncthreads();
     } else {
         if (tid < 6) { SoResult z; z.flag = 0; z.path_id = 0; z.ob_index = -1; z.dis_lat = 0; z.dis_lng = 0; store_path_obs(&po.around[tid], z, obs, false); }
-        if (tid == 0) { sh.n_ref = 0; po.sweep_side = 0; po.sweep_index = -1; }
+        if (tid == 0) { sh.n_ref = 0; po.sweep_side = 0; po.sweep_index = -1; po.navi_lanechg = 0; po.navi_lanechg_times = 0; }
         __syncthreads();
     }
     if (tid == 0) {       // Decision.cpp:187-201
@@ -589,13 +784,12 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         po.result.desstrVd = 0; po.result.light = dec.light; po.result.road_type = 0; po.result.sstop = 1; po.result._pad = 0;
         po.ob_dis_lat = r.dis_lat; po.ob_dis_lng = lon; po.ob_flag = r.flag; po.ob_pathid = r.path_id;
         if (r.flag) po.ob = obs[r.ob_index]; else { po.ob.x = 0; po.ob.y = 0; po.ob.type = 0; po.ob.radius = 0; }
-        po._pad[0] = 0; po._pad[1] = 0;
         st.his_behavior = dec.behavior;
         int cn = (count + 1) & 0xFF; if (cn % 100 == 1) cn = 1;
         st.count = cn;
         st.tick = st.tick + 1;
         if (!c.decision_stage) {
-            po.dec = dec; po.sweep_side = 0; po.sweep_index = -1;
+            po.dec = dec; po.sweep_side = 0; po.sweep_index = -1; po.navi_lanechg = 0; po.navi_lanechg_times = 0;
         }
     }
     if (!c.decision_stage && tid < 6) {

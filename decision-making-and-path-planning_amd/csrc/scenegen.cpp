@@ -42,6 +42,7 @@ extern "C" void pp_default_config(PlannerConfig* c, int grid_w, int grid_h)
     c->wgs_deg_per_m_lng = 1.0 / (111320.0 * std::cos(c->wgs_lat0 * kPi / 180.0));
     c->ID_MORE = 0;
     c->decision_stage = 1;
+    c->lanechg_stage = 1;
     c->grid_stage = 1;
     c->grid_w = grid_w; c->grid_h = grid_h;
     c->max_expansions = grid_w * grid_h;      // never binds unless lowered
@@ -68,10 +69,11 @@ extern "C" void pp_init_state(SceneState* st, int lane_num)
 
 // Layout of the pools this generator fills (fixed strides so scene s is self-contained):
 //   lane_pool : scene s owns [s*3*PP_GEN_LANE_PTS, (s+1)*3*PP_GEN_LANE_PTS): current, left, right lane
+//   lane_attr_pool : one lanechg_attribute byte per lane_pool point, same indexing
 //   ref_pool  : scene s owns [s*PP_GEN_REF_PTS,   (s+1)*PP_GEN_REF_PTS)
 //   obs_pool / mot_pool : scene s owns [s*n_obs, (s+1)*n_obs)
 extern "C" int pp_gen_scenes(const PlannerConfig* c, int first_scene, int n_scenes, int n_obs, int junction_every,
-                             SceneIn* in, GlobalPoint3D* lane_pool, GlobalPoint2D* ref_pool,
+                             SceneIn* in, GlobalPoint3D* lane_pool, uint8_t* lane_attr_pool, GlobalPoint2D* ref_pool,
                              ObPoint* obs_pool, ObMotion* mot_pool, SceneState* state)
 {
     if (!c || !in || !lane_pool || !ref_pool || n_scenes < 0 || n_obs < 0) return -1;
@@ -166,6 +168,23 @@ extern "C" int pp_gen_scenes(const PlannerConfig* c, int first_scene, int n_scen
         // grid engine
         si.grid_origin = { 0.0, 0.0 };
         si.goal = { rng.range(0.90 * S, 0.98 * S), rng.range(0.10 * Sy, 0.90 * Sy) };
+        // lane-change inputs (drawn last so that everything above keeps its values): the exit lanes the
+        // navigation allows, the decision period, and the per-point lane-change attribute of the map
+        {
+            static const uint16_t pat[8][3] = { {0, 0, 0}, {0, 0, 0}, {1, 0, 0}, {3, 0, 0}, {1, 2, 0}, {2, 3, 0}, {1, 2, 3}, {0, 0, 0} };
+            const int p = (int)(rng.next() & 7);
+            for (int k = 0; k < 3; k++) si.out_lane_no[k] = pat[p][k];
+            if (p < 2) si.out_lane_no[0] = (uint16_t)lane_num;      // ego already in an exit lane
+            si.period_last = 100.0;
+            const int run = 20 + (int)(rng.next() % 240);           // points ahead of the ego that keep the attribute
+            const int base = si.lanes.lanechg_attribute;
+            const int ahead = (rng.next() & 1) ? base : (base ? 3 : 0);
+            if (lane_attr_pool) {
+                uint8_t* a = lane_attr_pool + (size_t)s * 3 * PP_GEN_LANE_PTS;
+                for (int i = 0; i < 3 * PP_GEN_LANE_PTS; i++) a[i] = (uint8_t)base;
+                for (int i = 51; i < PP_GEN_LANE_PTS; i++) a[i] = (uint8_t)(i <= 50 + run ? ahead : 0);
+            }
+        }
         if (state) pp_init_state(&state[s], lane_num);
     }
     return 0;

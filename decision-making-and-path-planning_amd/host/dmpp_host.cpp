@@ -15,11 +15,12 @@ DmppStatus g_status;
 struct OneScene {
     SceneIn in{};
     vector<GlobalPoint3D> lanes;
+    vector<uint8_t> attr;           // lanechg_attribute per lane point
     vector<GlobalPoint2D> ref;
     vector<ObPoint> obs;
 };
 void build_scene(const LaneMap& m, const LocationOut& loc, const DecisionOut& dec, const vector<GlobalPoint2D>& ref,
-                 const vector<ObPoint>& obs, int stub_attribute, OneScene& s)
+                 const vector<ObPoint>& obs, int stub_attribute, OneScene& s, double period_last_ms = 100.0)
 {
     std::memset(&s.in, 0, sizeof(s.in));
     s.in.loc = loc; s.in.dec = dec;
@@ -31,6 +32,10 @@ void build_scene(const LaneMap& m, const LocationOut& loc, const DecisionOut& de
     s.in.lanes.right_off = (int)s.lanes.size(); s.in.lanes.right_n = (int)m.right.size();
     s.lanes.insert(s.lanes.end(), m.right.begin(), m.right.end());
     if (s.lanes.empty()) s.lanes.push_back(GlobalPoint3D{0, 0, 0});
+    s.attr.assign(s.lanes.size(), (uint8_t)m.lanechg_attribute);
+    for (size_t i = 0; i < m.cur_lanechg_attribute.size() && i < m.cur.size(); i++) s.attr[i] = m.cur_lanechg_attribute[i];
+    for (int i = 0; i < DMPP_LANESUM; i++) s.in.out_lane_no[i] = m.out_lane_no[i];
+    s.in.period_last = period_last_ms;
     s.in.lanes.lane_sum = m.lane_sum; s.in.lanes.lanechg_attribute = m.lanechg_attribute; s.in.lanes.lane_width = m.lane_width;
     s.ref = ref; if (s.ref.size() > DMPP_MAX_REFPATH) s.ref.resize(DMPP_MAX_REFPATH);
     s.in.ref_off = 0; s.in.ref_n = (int)s.ref.size(); s.in.dec.refpath_n = (int)s.ref.size();
@@ -49,7 +54,7 @@ int run_scene(OneScene& s, SceneState& st, PlanOut& out, GridOut* grid, bool dec
     if (!grid) c.grid_stage = 0;
     int rc = pp_set_config(h, &c);
     if (rc) return rc;
-    return pp_plan_tick_batch(h, 1, &s.in, s.obs.data(), nullptr, (int)s.obs.size(), s.lanes.data(), (int)s.lanes.size(),
+    return pp_plan_tick_batch(h, 1, &s.in, s.obs.data(), nullptr, (int)s.obs.size(), s.lanes.data(), s.attr.data(), (int)s.lanes.size(),
                               s.ref.data(), (int)s.ref.size(), &st, &out, grid);
 }
 }  // namespace
@@ -229,11 +234,12 @@ BYTE CDecision::startCDecisionThread() { return Device() ? 1 : 0; }
 void CDecision::Reset() { pp_init_state(&m_state, 1); }
 
 DecisionOutV CDecision::decide(const LocationOut& location, const vector<ObPoint>& obstacles,
-                               const vector<GlobalPoint2D>& junction_polyline, int stub_attribute, Path_Obs around[6])
+                               const vector<GlobalPoint2D>& junction_polyline, int stub_attribute, Path_Obs around[6],
+                               double period_last_ms)
 {
     OneScene s;
     DecisionOut none{};
-    build_scene(m_map, location, none, junction_polyline, obstacles, stub_attribute, s);
+    build_scene(m_map, location, none, junction_polyline, obstacles, stub_attribute, s, period_last_ms);
     if (m_state.tick == 0 && m_state.z_target_lanenum != location.lane_num) {
         m_state.z_target_lanenum = location.lane_num; m_state.d_his_target_lanenum = location.lane_num;
     }

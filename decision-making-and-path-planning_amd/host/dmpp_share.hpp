@@ -34,6 +34,11 @@ struct LaneMap {
     vector<GlobalPoint3D> cur, left, right;
     int lane_sum = 1, lanechg_attribute = 0;
     double lane_width = 3.75;
+    // decision_MapData[..][..][id].lanechg_attribute of every point of `cur` (Decision.cpp:1179); when shorter than
+    // `cur` the remainder takes `lanechg_attribute`
+    vector<BYTE> cur_lanechg_attribute;
+    // z_RoadNavi[path_num].out_lane_no (Decision.cpp:696): exit lanes of this road, 0-terminated
+    WORD out_lane_no[DMPP_LANESUM] = { 0 };
 };
 
 // Raised into a flag instead of AfxMessageBox (Decision.cpp:514): the reference's methods return void

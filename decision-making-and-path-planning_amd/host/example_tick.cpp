@@ -12,15 +12,18 @@ int main()
     // one generated scene -> the map / location / obstacle inputs of the class surface
     SceneIn in; SceneState st;
     std::vector<GlobalPoint3D> lanes(3 * PP_GEN_LANE_PTS);
+    std::vector<uint8_t> attr(3 * PP_GEN_LANE_PTS);
     std::vector<GlobalPoint2D> ref(PP_GEN_REF_PTS);
     std::vector<ObPoint> obs(64);
     std::vector<ObMotion> mot(64);
-    pp_gen_scenes(&cfg, 2, 1, 64, 0, &in, lanes.data(), ref.data(), obs.data(), mot.data(), &st);
+    pp_gen_scenes(&cfg, 2, 1, 64, 0, &in, lanes.data(), attr.data(), ref.data(), obs.data(), mot.data(), &st);
     LaneMap map;
     map.cur.assign(lanes.begin(), lanes.begin() + PP_GEN_LANE_PTS);
     if (in.lanes.left_n) map.left.assign(lanes.begin() + PP_GEN_LANE_PTS, lanes.begin() + 2 * PP_GEN_LANE_PTS);
     if (in.lanes.right_n) map.right.assign(lanes.begin() + 2 * PP_GEN_LANE_PTS, lanes.end());
     map.lane_sum = in.lanes.lane_sum; map.lanechg_attribute = in.lanes.lanechg_attribute; map.lane_width = in.lanes.lane_width;
+    map.cur_lanechg_attribute.assign(attr.begin(), attr.begin() + PP_GEN_LANE_PTS);
+    for (int i = 0; i < DMPP_LANESUM; i++) map.out_lane_no[i] = in.out_lane_no[i];
 
     CDecision& dec = CDecision::Instance();
     CPlanning& pl = CPlanning::Instance();

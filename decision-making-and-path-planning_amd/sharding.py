@@ -4,7 +4,7 @@ and a gather of results — torch.distributed over RCCL/xGMI on GPUs (backend "n
 No collective sits on the data path of a tick."""
 import numpy as np
 
-KEYS = ("scene_in", "lane_pool", "ref_pool", "obs_pool", "mot_pool", "state")
+KEYS = ("scene_in", "lane_pool", "attr_pool", "ref_pool", "obs_pool", "mot_pool", "state")
 
 
 def shard_nbytes(dm, n_scenes, n_obs):
@@ -12,6 +12,7 @@ def shard_nbytes(dm, n_scenes, n_obs):
     return {
         "scene_in": n_scenes * dm.SceneIn.itemsize,
         "lane_pool": n_scenes * 3 * dm.GEN_LANE_PTS * dm.GlobalPoint3D.itemsize,
+        "attr_pool": n_scenes * 3 * dm.GEN_LANE_PTS,
         "ref_pool": n_scenes * dm.GEN_REF_PTS * dm.GlobalPoint2D.itemsize,
         "obs_pool": max(n_scenes * n_obs, 1) * dm.ObPoint.itemsize,
         "mot_pool": max(n_scenes * n_obs, 1) * dm.ObMotion.itemsize,

@@ -49,7 +49,7 @@ typedef struct PlannerCaps {
 enum { PP_K_OBSTACLES = 0, PP_K_DECISION, PP_K_PLANNING, PP_K_RASTERISE, PP_K_SEARCH, PP_K_SCORE, PP_K_COUNT };
 /* device buffers addressable through pp_device_ptr (for RCCL scatter/gather by the caller) */
 enum { PP_BUF_SCENE_IN = 0, PP_BUF_LANE_POOL, PP_BUF_REF_POOL, PP_BUF_OBS_POOL, PP_BUF_MOT_POOL, PP_BUF_STATE,
-       PP_BUF_PLAN_OUT, PP_BUF_GRID_OUT, PP_BUF_GRID, PP_BUF_PATH, PP_BUF_ORDER, PP_BUF_COUNT };
+       PP_BUF_PLAN_OUT, PP_BUF_GRID_OUT, PP_BUF_GRID, PP_BUF_PATH, PP_BUF_ORDER, PP_BUF_LANE_ATTR, PP_BUF_COUNT };
 
 const char* pp_last_error(void);
 
@@ -58,10 +58,11 @@ const char* pp_last_error(void);
 void pp_default_config(PlannerConfig* cfg, int grid_w, int grid_h);
 /* Zeroed state with the constructor values of Planning.cpp:10. */
 void pp_init_state(SceneState* st, int lane_num);
-/* Seeded synthetic scenes.  Pools must hold n*3*PP_GEN_LANE_PTS lane points,
- * n*PP_GEN_REF_PTS refpath points, n*n_obs obstacles (mot_pool/state may be NULL). */
+/* Seeded synthetic scenes.  Pools must hold n*3*PP_GEN_LANE_PTS lane points (and as many
+ * lane attribute bytes), n*PP_GEN_REF_PTS refpath points, n*n_obs obstacles
+ * (lane_attr_pool/mot_pool/state may be NULL). */
 int  pp_gen_scenes(const PlannerConfig* cfg, int first_scene, int n_scenes, int n_obs, int junction_every,
-                   SceneIn* in, GlobalPoint3D* lane_pool, GlobalPoint2D* ref_pool,
+                   SceneIn* in, GlobalPoint3D* lane_pool, uint8_t* lane_attr_pool, GlobalPoint2D* ref_pool,
                    ObPoint* obs_pool, ObMotion* mot_pool, SceneState* state);
 
 /* ---- lifetime -------------------------------------------------------------------------- */
@@ -72,8 +73,10 @@ int  pp_set_config(pp_handle h, const PlannerConfig* cfg);   /* grid size / caps
 
 /* ---- resident-data path ------------------------------------------------------------------
  * Replaces the blackboard reads of Planning.cpp:95-112 / Decision.cpp:155-160. */
+/* lane_attr_pool[i] is decision_MapData[..][..][id].lanechg_attribute of lane point i (Decision.cpp:1179,1212):
+ * one byte per lane-pool point, same indexing.  Required when cfg.lanechg_stage is 1. */
 int  pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in,
-                   const GlobalPoint3D* lane_pool, int n_lane_pts,
+                   const GlobalPoint3D* lane_pool, const uint8_t* lane_attr_pool, int n_lane_pts,
                    const GlobalPoint2D* ref_pool, int n_ref_pts,
                    const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total);
 int  pp_set_state(pp_handle h, const SceneState* state, int n_scenes);
@@ -94,7 +97,7 @@ int  pp_get_refpath(pp_handle h, int scene, GlobalPoint2D* pts, int cap);
 /* ---- one-shot batch call (the SURVEY §8b signature): upload, tick, download ---------------- */
 int  pp_plan_tick_batch(pp_handle h, int n_scenes, const SceneIn* in,
                         const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total,
-                        const GlobalPoint3D* lane_pool, int n_lane_pts,
+                        const GlobalPoint3D* lane_pool, const uint8_t* lane_attr_pool, int n_lane_pts,
                         const GlobalPoint2D* ref_pool, int n_ref_pts,
                         SceneState* state_inout, PlanOut* out, GridOut* grid_out /* may be NULL */);
 

@@ -133,6 +133,7 @@ typedef struct SceneState {
     int32_t tick;                                   /* ticks elapsed; drives the dynamic-obstacle model (G4) */
     int32_t _pad;
     double  z_velocity_expect;                      /* Decision.h:47 */
+    double  leftlight_time, rightlight_time;        /* Decision.h:31-32: turn-signal timers, ms */
 } SceneState;
 
 /* ---- per-scene per-tick input ---------------------------------------------------- */
@@ -144,6 +145,9 @@ typedef struct SceneIn {
     int32_t obs_off, obs_n;   /* app->GetObj() snapshot: slice of the obstacle pool (Planning.cpp:111) */
     int32_t stub_attribute;   /* z_RoadNavi[path_num].stub_attribute, Decision.cpp:385 */
     int32_t _pad;
+    /* lane-change rule tree inputs (Decision.cpp:685-738, 1011-1772) */
+    uint16_t out_lane_no[DMPP_LANESUM]; /* z_RoadNavi[path_num].out_lane_no[]: exit lanes of this road, 0-terminated (Decision.cpp:696) */
+    double   period_last;     /* z_period_last: milliseconds since the previous decision tick (Decision.cpp:137) */
     /* grid engine (rows G1-G4; absent from the reference) */
     GlobalPoint2D grid_origin;/* world coordinates of the corner of cell (0,0) */
     GlobalPoint2D goal;       /* goal position, world */
@@ -190,7 +194,8 @@ typedef struct PlanOut {
     ObPoint        ob;
     int32_t        ob_flag, ob_pathid;
     int32_t        sweep_side, sweep_index;  /* which candidate of Decision.cpp:940-973 was accepted (-1 none) */
-    int32_t        _pad[2];
+    int32_t        navi_lanechg;             /* Nav_LaneChange result, Decision.cpp:685-738: 0 none, 1 left, 2 right */
+    int32_t        navi_lanechg_times;       /* CalcNaviLaneChgTimes, Decision.cpp:498-538 */
 } PlanOut;
 
 /* ---- every macro the reference uses but never defines ------------------ */
@@ -205,6 +210,7 @@ typedef struct PlannerConfig {
     double wgs_lat0, wgs_lng0, wgs_deg_per_m_lat, wgs_deg_per_m_lng;
     int32_t ID_MORE;                              /* Decision.cpp:581 */
     int32_t decision_stage;                       /* 1: run the CDecision corridor queries + sweep on device */
+    int32_t lanechg_stage;                        /* 1: run the lane-change rule tree (Decision.cpp:1017-1772) when the map allows a change */
     /* grid engine (build-defined) */
     int32_t grid_stage;                           /* 1: run G1-G3 every tick */
     int32_t grid_w, grid_h;                       /* cells */
@@ -212,6 +218,7 @@ typedef struct PlannerConfig {
     int32_t n_lattice, lookahead_cells;
     int32_t dynamic_obstacles;                    /* 1: obstacle j sits at p0 + v*(dyn_dt*tick) */
     int32_t force_replan;                         /* 1: config "replan every tick" (BASELINE configs[3]) */
+    int32_t _cfg_pad;
     double cell;                                  /* metres per cell */
     double inflate;                               /* added to every footprint radius when rasterising */
     double lattice_step, d_safe, w_col, w_curv, w_prog, w_off, dyn_dt;

@@ -530,11 +530,285 @@ static void orc_AroundObstacle(const PlannerConfig* c, const DecScratch* d, cons
     around_one(c, d->RR, d->nRR, obs, m, -0.5 * W, hv, &around[5]);            /* :842 */
 }
 
-/* Decision.cpp:898-1010 (LaneChg_Map == 0) and :1012-1015 (counters reset otherwise) */
-static void orc_BehaviorDecision(const PlannerConfig* c, const SceneIn* in, const DecScratch* d, const ObPoint* obs, int m,
-                                 double Width_CurLane, const Path_Obs* Path_Obs_F, SceneState* st, Behavior_Dec* Cur,
-                                 int* sweep_side, int* sweep_index)
+/* CalcNaviLaneChgTimes, Decision.cpp:498-538 (the AfxMessageBox diagnostics are UI and dropped; BYTE return) */
+static unsigned orc_CalcNaviLaneChgTimes(unsigned lanenum_cur, const uint16_t* outlanenum, int lanechgdir)
 {
+    int times = 5, times_tmp = 0;
+    lanenum_cur &= 0xffu;                                                      /* const BYTE lanenum_cur */
+    if (lanechgdir == 1) {
+        for (int i = 0; i < DMPP_LANESUM && outlanenum[i] != 0; i++) {
+            times_tmp = (int)lanenum_cur - (int)outlanenum[i];
+            if (times_tmp < times) times = times_tmp;
+        }
+    } else if (lanechgdir == 2) {
+        for (int i = 0; i < DMPP_LANESUM && outlanenum[i] != 0; i++) {
+            times_tmp = (int)outlanenum[i] - (int)lanenum_cur;
+            if (times_tmp < times) times = times_tmp;
+        }
+    }
+    return (unsigned)(times & 0xff);
+}
+
+/* Nav_LaneChange, Decision.cpp:685-738; the caller's initial values are those of Decision.cpp:234-235 */
+static void orc_Nav_LaneChange(const SceneIn* in, unsigned* Navi_LaneChg, unsigned* Navi_LaneChg_times)
+{
+    unsigned LaneNum_Cur = (unsigned)in->loc.lane_num;
+    const uint16_t* out = in->out_lane_no;
+    *Navi_LaneChg = 4; *Navi_LaneChg_times = 0;
+    for (unsigned i = 0; i < DMPP_LANESUM && out[i] != 0; i++)                 /* :696-703 */
+        if (LaneNum_Cur == out[i]) { *Navi_LaneChg = 0; break; }
+    unsigned out_lane_min = out[0], out_lane_max = 1;                          /* :706-715 */
+    for (int i = 0; i < DMPP_LANESUM; i++) if (out[i] > out_lane_max) out_lane_max = out[i];
+    if (*Navi_LaneChg == 4) {                                                  /* :719-737 */
+        if (LaneNum_Cur < out_lane_min) {
+            *Navi_LaneChg = 2;
+            *Navi_LaneChg_times = orc_CalcNaviLaneChgTimes(LaneNum_Cur, out, 2);
+        } else if (LaneNum_Cur > out_lane_max) {
+            *Navi_LaneChg = 1;
+            *Navi_LaneChg_times = orc_CalcNaviLaneChgTimes(LaneNum_Cur, out, 1);
+        } else {
+            *Navi_LaneChg = 0;
+        }
+    }
+}
+
+/* The "remaining lane-change length" loops of Decision.cpp:1178-1187 and the like:
+ *   for (WORD i = Id_CurLane; i < IdSum_CurLane - 1 && PRED(map[i + 1].lanechg_attribute); i++) dis += |p[i] p[i+1]|
+ * PRED as the compiler parses the reference's text (== binds tighter than &):
+ *   pred 0: attr == 1                      (:1179)
+ *   pred 1: attr & (0x01 == 0x01) = attr&1 (:1212,1459,1506) — and also attr & (0x02 == 0x02) (:1316,1344,1523)
+ *   pred 2: attr & (0x01 != 0x01) = 0      (:1477)
+ * A negative ego id starts at 0 (fence: the reference would wrap it to 65535 and skip the loop body on
+ * out-of-range reads). */
+static double orc_lanechg_remaining(const GlobalPoint3D* cur, const uint8_t* attr, int Id_CurLane, int IdSum_CurLane, int pred)
+{
+    double dis_chg1 = 0;
+    for (int i = Id_CurLane < 0 ? 0 : Id_CurLane; i < IdSum_CurLane - 1; i++) {
+        int a = attr ? attr[i + 1] : 0, ok;
+        if (pred == 0) ok = (a == 1);
+        else if (pred == 1) ok = (a & 1);
+        else ok = (a & 0);
+        if (!ok) break;
+        GlobalPoint2D pt = { cur[i].x, cur[i].y }, pt1 = { cur[i + 1].x, cur[i + 1].y };
+        dis_chg1 += orc_CalcDistance(pt, pt1);
+    }
+    return dis_chg1;
+}
+
+#define KEEP_LANE()   do { Cur->behavior = 1; Cur->target_lanenum = LaneNum_Cur; Cur->lanechg_status = 0; } while (0)
+#define KEEP_LANE_NS() do { Cur->behavior = 1; Cur->target_lanenum = LaneNum_Cur; } while (0)   /* branches that leave lanechg_status alone */
+#define CAP_LEFT(v)   do { st->leftlight_time += period; if (st->leftlight_time > 2000) st->leftlight_time = (v); } while (0)
+
+/* Lane-change rule tree, Decision.cpp:1017-1772 (the map allows a lane change at the ego point). */
+static void orc_LaneChangeTree(const SceneIn* in, const GlobalPoint3D* lane_pool, const uint8_t* attr_pool,
+                               const Path_Obs* around, unsigned Navi_LaneChg, const Behavior_Dec* His,
+                               SceneState* st, Behavior_Dec* Cur)
+{
+    int LaneNum_Cur = in->loc.lane_num;
+    const int LaneChg_Map = in->lanes.lanechg_attribute, LaneSum = in->lanes.lane_sum;
+    const int Id_CurLane = in->loc.id[clampi(LaneNum_Cur - 1, 0, DMPP_LANESUM - 1)];
+    const int IdSum_CurLane = in->lanes.cur_n;
+    const GlobalPoint3D* cur = lane_pool + in->lanes.cur_off;
+    const uint8_t* attr = attr_pool ? attr_pool + in->lanes.cur_off : NULL;
+    const uint16_t* out = in->out_lane_no;
+    const double period = in->period_last;
+    const double F = around[0].Ob_Pose.dis_lng, LF = around[2].Ob_Pose.dis_lng, LR = around[3].Ob_Pose.dis_lng;
+    const double RF = around[4].Ob_Pose.dis_lng, RR = around[5].Ob_Pose.dis_lng;
+    int z_light_status = Cur->light_status;       /* the member the tree reads at :1193 (= Cur.light_status, :287) */
+
+    if (Cur->lanechg_status == 0) {                                            /* :1018 */
+        if (Navi_LaneChg != 0) {                                               /* :1021 */
+            if (Navi_LaneChg == 1) {
+                if (LaneChg_Map == 1 || LaneChg_Map == 3) {                    /* :1027 */
+                    Cur->behavior_to_dlg = 2;
+                    if (Cur->light_status != 1) { Cur->light_status = 1; st->leftlight_time = 0; }
+                    st->leftlight_time += period;                              /* :1035 */
+                    if (LF > F + 10 || LF > 40) {                              /* :1038 */
+                        if (LR > 15) {
+                            if (st->leftlight_time > 2000) {                   /* :1044 */
+                                Cur->behavior = 2; Cur->target_lanenum = LaneNum_Cur - 1; Cur->lanechg_status = 1;
+                            } else KEEP_LANE();
+                        } else KEEP_LANE();
+                    } else KEEP_LANE();
+                } else { KEEP_LANE(); Cur->behavior_to_dlg = 4; }              /* :1077-1083 */
+            } else if (Navi_LaneChg == 2) {                                    /* :1086 */
+                if (LaneChg_Map == 2 || LaneChg_Map == 3) {
+                    Cur->behavior_to_dlg = 3;
+                    if (Cur->light_status != 2) { Cur->lanechg_status = 2; st->rightlight_time = 0; }  /* :1092-1096 as written */
+                    st->rightlight_time += period;
+                    if (RF > F + 10 || RF > 40) {                              /* :1100 */
+                        if (RR > 15) {
+                            if (st->rightlight_time >= 2000) {                 /* :1106 */
+                                Cur->behavior = 3; Cur->target_lanenum = LaneNum_Cur + 1; Cur->lanechg_status = 1;
+                            } else KEEP_LANE();
+                        } else KEEP_LANE();
+                    } else KEEP_LANE();
+                } else { KEEP_LANE(); Cur->behavior_to_dlg = 4; }              /* :1135-1141 */
+            }
+        } else {                                                               /* :1146 no navigation demand */
+            if (F < (2 * 10 + 5)) {                                            /* :1149 */
+                st->frontobs_time++;
+                if (st->frontobs_time > 2) {
+                    st->frontobs_time = 3;
+                    if (LaneChg_Map == 1) {                                    /* :1157 */
+                        if (LaneNum_Cur > 1) {
+                            Cur->behavior_to_dlg = 5;
+                            int no_back_flag = 1;                              /* :1165-1172 */
+                            for (int i = 0; i < DMPP_LANESUM && out[i] != 0; i++) if (out[i] == LaneNum_Cur - 1) no_back_flag = 0;
+                            int chg_condition_flag = 0;
+                            if (no_back_flag) {
+                                double dis_chg1 = orc_lanechg_remaining(cur, attr, Id_CurLane, IdSum_CurLane, 0);  /* :1179 */
+                                if (dis_chg1 > 60) {
+                                    chg_condition_flag = 1;
+                                    if (z_light_status != 1) { z_light_status = 1; st->leftlight_time = 0; }   /* :1193-1197 */
+                                    CAP_LEFT(2000);
+                                } else z_light_status = 0;
+                            } else {
+                                double dis_chg1 = orc_lanechg_remaining(cur, attr, Id_CurLane, IdSum_CurLane, 1);  /* :1212 */
+                                if (dis_chg1 > 15) {
+                                    chg_condition_flag = 1;
+                                    if (Cur->light_status != 1) { Cur->light_status = 1; st->leftlight_time = 0; }
+                                    CAP_LEFT(2100);                            /* :1230-1233 */
+                                } else Cur->light_status = 0;
+                            }
+                            if (chg_condition_flag) {                          /* :1242 */
+                                if (LF > F + 10) {
+                                    if (LR > 10) {
+                                        if (st->leftlight_time > 1500) {
+                                            st->frontobs_time = 0;
+                                            Cur->behavior = 2; Cur->target_lanenum = LaneNum_Cur - 1; Cur->lanechg_status = 1;
+                                        } else KEEP_LANE();
+                                    } else KEEP_LANE();
+                                } else KEEP_LANE();
+                            } else KEEP_LANE();
+                        } else KEEP_LANE();                                    /* :1287-1292 */
+                    } else if (LaneChg_Map == 2) {                             /* :1296 */
+                        if (LaneNum_Cur < LaneSum) {
+                            Cur->behavior_to_dlg = 6;
+                            int no_back_flag = 1;                              /* :1304-1309 (tests the LEFT neighbour, as written) */
+                            for (int i = 0; i < DMPP_LANESUM && out[i] != 0; i++) if (out[i] == LaneNum_Cur - 1) no_back_flag = 0;
+                            int chg_condition_flag = 0;
+                            if (no_back_flag) {
+                                double dis_chg1 = orc_lanechg_remaining(cur, attr, Id_CurLane, IdSum_CurLane, 1);  /* :1316 */
+                                if (dis_chg1 > 50) {
+                                    chg_condition_flag = 1;
+                                    if (Cur->light_status != 2) { Cur->light_status = 2; st->leftlight_time = 0; }
+                                    CAP_LEFT(2000);
+                                }
+                            } else {
+                                double dis_chg1 = orc_lanechg_remaining(cur, attr, Id_CurLane, IdSum_CurLane, 1);  /* :1344 */
+                                if (dis_chg1 > 10) {
+                                    chg_condition_flag = 1;
+                                    if (Cur->light_status != 1) { Cur->light_status = 1; st->leftlight_time = 0; }  /* :1356-1360 */
+                                    CAP_LEFT(2000);
+                                }
+                            }
+                            if (chg_condition_flag) {                          /* :1370 */
+                                if (RF > F + 10) {
+                                    if (RR > 10) {
+                                        if (st->leftlight_time > 1500) {
+                                            st->frontobs_time = 0;
+                                            Cur->behavior = 3; Cur->target_lanenum = LaneNum_Cur + 1; Cur->lanechg_status = 1;
+                                        } else KEEP_LANE();
+                                    } else KEEP_LANE();
+                                } else KEEP_LANE();
+                            } else KEEP_LANE();
+                        } else KEEP_LANE();                                    /* :1417-1422 */
+                    } else if (LaneChg_Map == 3) {                             /* :1426 (z_behavior_to_dlg = 7 is overwritten at :312) */
+                        int no_back_leftchg_flag = 1, no_back_rightchg_flag = 1;
+                        for (int i = 0; i < DMPP_LANESUM && out[i] != 0; i++) if (out[i] == LaneNum_Cur - 1) no_back_leftchg_flag = 0;
+                        for (int i = 0; i < DMPP_LANESUM && out[i] != 0; i++) if (out[i] == LaneNum_Cur + 1) no_back_rightchg_flag = 0;
+                        int leftchg_condition_flag = 0;                        /* :1453-1495 */
+                        if (LaneNum_Cur > 1) {
+                            if (no_back_leftchg_flag) {
+                                if (orc_lanechg_remaining(cur, attr, Id_CurLane, IdSum_CurLane, 1) > 50) leftchg_condition_flag = 1;
+                            } else {
+                                if (orc_lanechg_remaining(cur, attr, Id_CurLane, IdSum_CurLane, 2) > 10) leftchg_condition_flag = 1;
+                            }
+                        }
+                        int rightchg_condition_flag = 0;                       /* :1500-1541 */
+                        if (LaneNum_Cur < LaneSum) {
+                            if (no_back_rightchg_flag) {
+                                if (orc_lanechg_remaining(cur, attr, Id_CurLane, IdSum_CurLane, 1) > 50) rightchg_condition_flag = 1;
+                            } else {
+                                if (orc_lanechg_remaining(cur, attr, Id_CurLane, IdSum_CurLane, 1) > 10) rightchg_condition_flag = 1;
+                            }
+                        }
+                        if (leftchg_condition_flag && !no_back_leftchg_flag) { /* :1545 */
+                            if (Cur->lanechg_status != 1) { Cur->light_status = 1; st->leftlight_time = 0; }
+                            CAP_LEFT(2000);
+                            if (LF > F + 10) {
+                                if (LR > 10) {
+                                    if (st->leftlight_time > 2000) {
+                                        st->frontobs_time = 0;
+                                        Cur->behavior = 2; Cur->target_lanenum = LaneNum_Cur - 1; Cur->lanechg_status = 1;
+                                    } else KEEP_LANE();
+                                } else KEEP_LANE();
+                            } else KEEP_LANE();
+                        } else if (rightchg_condition_flag && !no_back_rightchg_flag) {   /* :1596 */
+                            if (Cur->light_status != 2) { Cur->light_status = 2; st->leftlight_time = 0; }
+                            CAP_LEFT(2000);
+                            if (RF > F + 10) {                                 /* no else branch, :1609-1635 */
+                                if (RR > 10) {
+                                    if (st->leftlight_time > 2000) {
+                                        st->frontobs_time = 0;
+                                        Cur->behavior = 3; Cur->target_lanenum = LaneNum_Cur + 1; Cur->lanechg_status = 1;
+                                    } else KEEP_LANE_NS();
+                                } else KEEP_LANE_NS();
+                            }
+                        } else if (leftchg_condition_flag) {                   /* :1638 */
+                            if (Cur->light_status != 1) { Cur->lanechg_status = 1; st->leftlight_time = 0; }   /* :1640-1644 as written */
+                            CAP_LEFT(2000);
+                            if (LF > F + 10) {
+                                if (LR > 10) {
+                                    if (st->leftlight_time > 2000) {
+                                        st->frontobs_time = 0;
+                                        Cur->behavior = 2; Cur->target_lanenum = LaneNum_Cur - 1; Cur->lanechg_status = 1;
+                                    } else KEEP_LANE_NS();
+                                } else KEEP_LANE_NS();
+                            } else KEEP_LANE_NS();
+                        } else if (rightchg_condition_flag) {                  /* :1688 */
+                            if (Cur->light_status != 2) { Cur->light_status = 2; st->leftlight_time = 0; }
+                            CAP_LEFT(2000);
+                            if (RF > F + 10) {                                 /* no else branch, :1702-1729 */
+                                if (RR > 10) {
+                                    if (st->leftlight_time > 2000) {
+                                        st->frontobs_time = 0;
+                                        Cur->behavior = 3;
+                                        Cur->target_lanenum = LaneNum_Cur = 1; /* :1712 as written */
+                                        Cur->lanechg_status = 1;
+                                    } else KEEP_LANE_NS();
+                                } else KEEP_LANE_NS();
+                            }
+                        } else KEEP_LANE();                                    /* :1731-1736 */
+                    }
+                } else KEEP_LANE();                                            /* :1741-1746 */
+            } else {                                                           /* :1749-1756 */
+                st->frontobs_time = 0;
+                Cur->behavior_to_dlg = 8;
+                KEEP_LANE();
+            }
+        }
+    } else if (Cur->lanechg_status == 1) {                                     /* :1760-1771 */
+        Cur->behavior_to_dlg = 9;
+        if (Cur->target_lanenum == LaneNum_Cur) { Cur->lanechg_status = 0; Cur->light_status = 0; }
+        Cur->behavior = His->behavior;
+        Cur->target_lanenum = His->target_lanenum;
+        Cur->light_status = His->light_status;
+    }
+    (void)z_light_status;
+}
+#undef KEEP_LANE
+#undef KEEP_LANE_NS
+#undef CAP_LEFT
+
+/* Decision.cpp:898-1010 (LaneChg_Map == 0) and :1012-1015 (counters reset otherwise) */
+static void orc_BehaviorDecision(const PlannerConfig* c, const SceneIn* in, const GlobalPoint3D* lane_pool, const uint8_t* attr_pool,
+                                 const DecScratch* d, const ObPoint* obs, int m,
+                                 double Width_CurLane, const Path_Obs* around, unsigned Navi_LaneChg, const Behavior_Dec* His,
+                                 SceneState* st, Behavior_Dec* Cur, int* sweep_side, int* sweep_index)
+{
+    const Path_Obs* Path_Obs_F = &around[0];
     int LaneNum_Cur = in->loc.lane_num;
     int LaneChg_Map = in->lanes.lanechg_attribute;
     *sweep_side = 0; *sweep_index = -1;
@@ -587,16 +861,19 @@ static void orc_BehaviorDecision(const PlannerConfig* c, const SceneIn* in, cons
     } else {
         st->no_obsaviod_time = 0;                                             /* :1014-1015 */
         st->obsavoid_time = 0;
-        /* lane-change rule tree (Decision.cpp:1017-1772) is out of scope: behaviour passes through */
+        if (c->lanechg_stage) orc_LaneChangeTree(in, lane_pool, attr_pool, around, Navi_LaneChg, His, st, Cur);  /* :1017-1772 */
     }
 }
 
 /* Decision.cpp:216-315 restricted to the in-scope calls */
-static void orc_SegmentDecision(const PlannerConfig* c, const SceneIn* in, const GlobalPoint3D* lane_pool,
+static void orc_SegmentDecision(const PlannerConfig* c, const SceneIn* in, const GlobalPoint3D* lane_pool, const uint8_t* attr_pool,
                                 const ObPoint* obs, int m, SceneState* st, DecScratch* d, PlanOut* po)
 {
     double Width_CurLane = 0;
-    Behavior_Dec Cur;
+    Behavior_Dec Cur, His;
+    unsigned Navi_LaneChg = 4, Navi_LaneChg_times = 0;                         /* :234-235 */
+    orc_Nav_LaneChange(in, &Navi_LaneChg, &Navi_LaneChg_times);                /* :268 */
+    po->navi_lanechg = (int32_t)Navi_LaneChg; po->navi_lanechg_times = (int32_t)Navi_LaneChg_times;
     orc_LoadRefPath(c, in, lane_pool, d, &Width_CurLane);                      /* :271 */
     orc_AroundObstacle(c, d, obs, m, Width_CurLane, po->around);               /* :274 */
     Cur.behavior = st->z_behavior;                                             /* :286-291 */
@@ -605,7 +882,10 @@ static void orc_SegmentDecision(const PlannerConfig* c, const SceneIn* in, const
     Cur.lanechg_status = st->z_segment_lanechg_status;
     Cur.obsavoid_status = st->z_segment_obsavoid_status;
     Cur.behavior_to_dlg = st->z_behavior_to_dlg;
-    orc_BehaviorDecision(c, in, d, obs, m, Width_CurLane, &po->around[0], st, &Cur, &po->sweep_side, &po->sweep_index); /* :298 */
+    memset(&His, 0, sizeof(His));                                              /* :265, :293-295 */
+    His.behavior = st->d_his_behavior; His.light_status = st->d_his_light_status; His.target_lanenum = st->d_his_target_lanenum;
+    orc_BehaviorDecision(c, in, lane_pool, attr_pool, d, obs, m, Width_CurLane, po->around, Navi_LaneChg, &His, st, &Cur,
+                         &po->sweep_side, &po->sweep_index);                   /* :298 */
     st->z_velocity_expect = (Cur.behavior == 4 || Cur.behavior == 5) ? 5 : 10; /* SpeedDecision :1781-1793 */
     /* RefPath :1801-1816 */
     const GlobalPoint2D* src = d->F; int n = d->nF;
@@ -668,8 +948,8 @@ static void orc_StubDecisions(const PlannerConfig* c, const SceneIn* in, const G
 
 /* ------------------------------------------------------------------------------ */
 /* The tick: Decision.cpp:172-205 (decision stage) then Planning.cpp:114-223. */
-void orc_plan_tick(const PlannerConfig* c, const SceneIn* in, const GlobalPoint3D* lane_pool, const GlobalPoint2D* ref_pool,
-                   const ObPoint* obs_pool, const ObMotion* mot_pool, SceneState* st, PlanOut* po, GridOut* go,
+void orc_plan_tick(const PlannerConfig* c, const SceneIn* in, const GlobalPoint3D* lane_pool, const uint8_t* attr_pool,
+                   const GlobalPoint2D* ref_pool, const ObPoint* obs_pool, const ObMotion* mot_pool, SceneState* st, PlanOut* po, GridOut* go,
                    uint8_t* grid_scratch, int32_t* order, int order_cap, int32_t* path, int path_cap)
 {
     const LocationOut* loc = &in->loc;
@@ -685,7 +965,7 @@ void orc_plan_tick(const PlannerConfig* c, const SceneIn* in, const GlobalPoint3
     /* ---- decision stage ---- */
     if (c->decision_stage) {
         switch (loc->pos) {                                                    /* Decision.cpp:172-185 */
-        case 0: orc_SegmentDecision(c, in, lane_pool, obs, m, st, d, po); break;
+        case 0: orc_SegmentDecision(c, in, lane_pool, attr_pool, obs, m, st, d, po); break;
         case 1: case 2: orc_StubDecisions(c, in, lane_pool, ref_pool, obs, m, st, d, po); break;
         default: d->n_ref = 0; break;
         }

@@ -60,12 +60,12 @@ int  orc_cell_of(const PlannerConfig*, GlobalPoint2D origin, double x, double y)
 /* ---- whole tick for one scene / a batch ------------------------------------------- */
 /* grid_scratch: grid_w*grid_h bytes (may be NULL when cfg->grid_stage == 0);
  * grid_out may be NULL.  order/path as in orc_grid_search. */
-void orc_plan_tick(const PlannerConfig*, const SceneIn*, const GlobalPoint3D* lane_pool, const GlobalPoint2D* ref_pool,
-                   const ObPoint* obs_pool, const ObMotion* mot_pool, SceneState*, PlanOut*, GridOut*,
+void orc_plan_tick(const PlannerConfig*, const SceneIn*, const GlobalPoint3D* lane_pool, const uint8_t* lane_attr_pool,
+                   const GlobalPoint2D* ref_pool, const ObPoint* obs_pool, const ObMotion* mot_pool, SceneState*, PlanOut*, GridOut*,
                    uint8_t* grid_scratch, int32_t* order, int order_cap, int32_t* path, int path_cap);
 /* runs scenes [0,n) on n_threads pthreads; grids (n * w*h bytes) may be NULL -> internal scratch */
 void orc_plan_tick_batch(const PlannerConfig*, int n, const SceneIn*, const GlobalPoint3D* lane_pool,
-                         const GlobalPoint2D* ref_pool, const ObPoint* obs_pool, const ObMotion* mot_pool,
+                         const uint8_t* lane_attr_pool, const GlobalPoint2D* ref_pool, const ObPoint* obs_pool, const ObMotion* mot_pool,
                          SceneState*, PlanOut*, GridOut*, uint8_t* grids, int n_threads);
 
 #ifdef __cplusplus

@@ -9,7 +9,7 @@
 
 typedef struct Job {
     const PlannerConfig* c; int lo, hi;
-    const SceneIn* in; const GlobalPoint3D* lane_pool; const GlobalPoint2D* ref_pool;
+    const SceneIn* in; const GlobalPoint3D* lane_pool; const uint8_t* attr_pool; const GlobalPoint2D* ref_pool;
     const ObPoint* obs_pool; const ObMotion* mot_pool;
     SceneState* st; PlanOut* po; GridOut* go; uint8_t* grids;
 } Job;
@@ -22,7 +22,7 @@ static void* worker(void* arg)
     if (j->c->grid_stage && !j->grids) scratch = (uint8_t*)malloc(cells);
     for (int s = j->lo; s < j->hi; s++) {
         uint8_t* g = j->grids ? j->grids + (size_t)s * cells : scratch;
-        orc_plan_tick(j->c, &j->in[s], j->lane_pool, j->ref_pool, j->obs_pool, j->mot_pool, &j->st[s], &j->po[s],
+        orc_plan_tick(j->c, &j->in[s], j->lane_pool, j->attr_pool, j->ref_pool, j->obs_pool, j->mot_pool, &j->st[s], &j->po[s],
                       j->go ? &j->go[s] : NULL, g, NULL, 0, NULL, 0);
     }
     free(scratch);
@@ -30,7 +30,7 @@ static void* worker(void* arg)
 }
 
 void orc_plan_tick_batch(const PlannerConfig* c, int n, const SceneIn* in, const GlobalPoint3D* lane_pool,
-                         const GlobalPoint2D* ref_pool, const ObPoint* obs_pool, const ObMotion* mot_pool,
+                         const uint8_t* attr_pool, const GlobalPoint2D* ref_pool, const ObPoint* obs_pool, const ObMotion* mot_pool,
                          SceneState* st, PlanOut* po, GridOut* go, uint8_t* grids, int n_threads)
 {
     if (n_threads < 1) n_threads = 1;
@@ -40,7 +40,7 @@ void orc_plan_tick_batch(const PlannerConfig* c, int n, const SceneIn* in, const
     for (int t = 0; t < n_threads; t++) {
         Job* j = &jobs[t];
         j->c = c; j->lo = (int)((long long)n * t / n_threads); j->hi = (int)((long long)n * (t + 1) / n_threads);
-        j->in = in; j->lane_pool = lane_pool; j->ref_pool = ref_pool; j->obs_pool = obs_pool; j->mot_pool = mot_pool;
+        j->in = in; j->lane_pool = lane_pool; j->attr_pool = attr_pool; j->ref_pool = ref_pool; j->obs_pool = obs_pool; j->mot_pool = mot_pool;
         j->st = st; j->po = po; j->go = go; j->grids = grids;
         if (n_threads == 1) worker(j); else pthread_create(&th[t], NULL, worker, j);
     }

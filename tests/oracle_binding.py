@@ -51,8 +51,8 @@ class Oracle:
         L.orc_grid_score.argtypes = [vp, vp, vp, ci, vp, vp]
         L.orc_cell_of.argtypes = [vp, P2, cd, cd]
         L.orc_effective_obstacles.argtypes = [vp, vp, vp, ci, ci, vp]
-        L.orc_plan_tick.argtypes = [vp] * 9 + [vp, vp, ci, vp, ci]
-        L.orc_plan_tick_batch.argtypes = [vp, ci] + [vp] * 9 + [ci]
+        L.orc_plan_tick.argtypes = [vp] * 10 + [vp, vp, ci, vp, ci]
+        L.orc_plan_tick_batch.argtypes = [vp, ci] + [vp] * 10 + [ci]
 
     # ---- scalar helpers ----
     def GetLatDis(self, cfg, cur, pt, nxt):
@@ -138,8 +138,8 @@ class Oracle:
         grids = None
         if keep_grids:
             grids = np.zeros((n, int(cfg["grid_h"][0]), int(cfg["grid_w"][0])), np.uint8)
-        self.L.orc_plan_tick_batch(_p(cfg), n, _p(sc["scene_in"]), _p(sc["lane_pool"]), _p(sc["ref_pool"]), _p(sc["obs_pool"]),
-                                   _p(sc["mot_pool"]), _p(state), _p(plan), _p(gout), _p(grids), n_threads)
+        self.L.orc_plan_tick_batch(_p(cfg), n, _p(sc["scene_in"]), _p(sc["lane_pool"]), _p(sc.get("attr_pool")), _p(sc["ref_pool"]),
+                                   _p(sc["obs_pool"]), _p(sc["mot_pool"]), _p(state), _p(plan), _p(gout), _p(grids), n_threads)
         return plan, gout, grids
 
     def plan_tick_one(self, cfg, sc, s, state, order_cap=0):
@@ -149,7 +149,7 @@ class Oracle:
         mp = int(cfg["max_path"][0])
         path = np.zeros(mp, np.int32)
         grid = np.zeros((int(cfg["grid_h"][0]), int(cfg["grid_w"][0])), np.uint8)
-        self.L.orc_plan_tick(_p(cfg), sc["scene_in"][s:s + 1].ctypes.data, _p(sc["lane_pool"]), _p(sc["ref_pool"]),
+        self.L.orc_plan_tick(_p(cfg), sc["scene_in"][s:s + 1].ctypes.data, _p(sc["lane_pool"]), _p(sc.get("attr_pool")), _p(sc["ref_pool"]),
                              _p(sc["obs_pool"]), _p(sc["mot_pool"]), state[s:s + 1].ctypes.data, _p(plan), _p(gout), _p(grid),
                              _p(order) if order_cap else None, order_cap, _p(path), mp)
         ne = int(gout["n_expanded"][0])

@@ -378,3 +378,68 @@ def test_zero_and_one_scene(dm, oracle):
     plan_g, gout_g = pl.plan_tick_batch(sc, st_g)
     plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st_o)
     assert not (compare(plan_g, plan_o) + compare(st_g, st_o) + compare(gout_g, gout_o))
+
+
+# ---- lane-change rule tree (Decision.cpp:1011-1772) --------------------------------
+def test_lanechange_known_scenes(dm, oracle):
+    """Every hand-built scene of test_lanechange_kat.py, device against oracle, 7 ticks each, with the
+    localisation switching to the target lane once a change has been decided."""
+    import lanechange_scenes as lcs
+    cfg = dm.default_config(128)
+    cfg["grid_stage"] = 0
+    pl = dm.Planner(cfg, device=0, max_scenes=1, max_obs_total=8)
+    changed = 0
+    for k, kw in enumerate(lcs.SCENARIOS):
+        sc = lcs.make_scene(dm, cfg, **kw)
+        st_o = sc["state"].copy()
+        pl.set_state(sc["state"])
+        for t in range(7):
+            pl.set_scenes(sc)
+            pl.tick(sync=True)
+            plan_g, st_g = pl.get_plan(), pl.get_state()
+            plan_o, _, _ = oracle.plan_tick_batch(cfg, sc, st_o, want_grid=False)
+            bad = compare(plan_g, plan_o, "plan") + compare(st_g, st_o, "state")
+            assert not bad, f"scenario {k} {kw} tick {t}\n" + "\n".join(bad[:10])
+            tgt = int(st_o["z_target_lanenum"][0])
+            if int(st_o["z_segment_lanechg_status"][0]) == 1 and int(st_o["z_behavior"][0]) in (2, 3) and 1 <= tgt <= 3 \
+                    and tgt != int(sc["scene_in"]["loc"]["lane_num"][0]) and t >= 4:
+                lcs.switch_lane(dm, sc, tgt)
+                changed += 1
+    assert changed >= 5            # the scenes do reach the "changing lanes" state
+
+
+def test_lanechange_generated_scenes(dm, oracle):
+    """Generated scenes with mixed decision periods: 30 ticks, the ego advancing along its lane, every tick compared."""
+    cfg = dm.default_config(128)
+    cfg["grid_stage"] = 0
+    n = 1024
+    sc = dm.gen_scenes(cfg, 4096, n, 64, junction_every=8)
+    sc["scene_in"]["period_last"] = np.array([100.0, 700.0, 900.0, 1600.0, 2500.0])[np.arange(n) % 5]
+    seen_b, seen_dlg = set(), set()
+
+    def mutate(sc, t):
+        if t and t % 3 == 0:
+            move_ego(sc, 2)
+
+    pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=30, mutate=mutate)
+    for t, r in enumerate(res):
+        _assert_tick(r, f"tick {t}")
+        seen_b |= set(np.unique(r[4]["z_behavior"]).tolist())
+        seen_dlg |= set(np.unique(r[4]["z_behavior_to_dlg"]).tolist())
+    assert {1, 2, 3, 4, 5} <= seen_b, seen_b                  # keep, both lane changes, both avoidance sides
+    assert {2, 3, 4, 5, 6, 8, 9} <= seen_dlg, seen_dlg        # every panel code of the rule tree that generated scenes reach
+
+
+def test_lanechange_needs_attributes(dm):
+    cfg = dm.default_config(128)
+    sc = dm.gen_scenes(cfg, 0, 2, 8)
+    pl = dm.Planner(cfg, device=0, max_scenes=2, max_obs_total=16)
+    noattr = dict(sc)
+    noattr["attr_pool"] = None
+    pl.set_scenes(noattr)
+    pl.set_state(sc["state"])
+    with pytest.raises(dm.PlannerError, match="lane attribute"):
+        pl.tick(sync=True)
+    cfg["lanechg_stage"] = 0
+    pl.set_config(cfg)
+    pl.tick(sync=True)              # the rule tree switched off: no attributes needed

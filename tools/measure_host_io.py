@@ -21,6 +21,6 @@ K = 20
 for _ in range(K):
     pl.plan_tick_batch(sc, st)
 dt = (time.perf_counter() - t0) / K
-up = sum(sc[k].nbytes for k in ("scene_in", "lane_pool", "ref_pool", "obs_pool", "mot_pool")) + st.nbytes
+up = sum(sc[k].nbytes for k in ("scene_in", "lane_pool", "attr_pool", "ref_pool", "obs_pool", "mot_pool")) + st.nbytes
 down = n * (dm.PlanOut.itemsize + dm.SceneState.itemsize + dm.GridOut.itemsize)
 print(f"host-buffer tick: {dt*1e3:.3f} ms for {n} scenes = {n/dt:.0f} ticks/s ; {up/1e6:.1f} MB up + {down/1e6:.1f} MB down per tick")

@@ -119,22 +119,30 @@ int setup_grid_launch(pp_planner* h)
     // rasterise: bands of <= 65536 cells (8 KiB of LDS bits), whole rows
     int band = 65536 / c.grid_w; if (band < 1) band = 1; if (band > c.grid_h) band = c.grid_h;
     h->raster_band_rows = band;
-    // search: bitmap in LDS when it fits next to nothing else, else in HBM
+    // search: word summaries of both bitmap views always in LDS; the bitmaps too when they fit, else in HBM
     const size_t bm_bytes = 2 * (N / 8);              // row-major + column-major obstacle bits
+    const size_t ww = (size_t)c.grid_w / 32, hw = (size_t)c.grid_h / 32;
+    const size_t nz_bytes = 4 * ((size_t)c.grid_h * ((ww + 31) / 32) + (size_t)c.grid_w * ((hw + 31) / 32));
+    const size_t static_lds = 12288;                  // open list, closed hash, small tables (k_search's __shared__ arrays: 11.9 KB)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
-    const size_t lds_max = prop.sharedMemPerBlock;        // 64 KiB default, 160 KiB opt-in on gfx950
-    size_t optin = lds_max;
+    size_t lds_max = prop.sharedMemPerBlock;          // 64 KiB default, 160 KiB opt-in on gfx950
     {
         int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && v > 0) optin = (size_t)v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && (size_t)v > lds_max) lds_max = (size_t)v;
     }
-    h->search_gbm = bm_bytes + 8448 > (optin > lds_max ? optin : lds_max) || bm_bytes > 160u * 1024u - 8448u;   // + the open list
-    h->search_lds = h->search_gbm ? 0 : (int)bm_bytes;
-    if (!h->search_gbm && bm_bytes > 48u * 1024u) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_search<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
-        if (e != hipSuccess) { (void)hipGetLastError(); h->search_gbm = true; h->search_lds = 0; }
+    if (lds_max > 160u * 1024u) lds_max = 160u * 1024u;
+    if (nz_bytes + static_lds > lds_max) return fail(PP_ERR_CAPACITY, "grid too large for the search kernel's LDS tables");
+    h->search_gbm = bm_bytes + nz_bytes + static_lds > lds_max;
+    h->search_lds = (int)(nz_bytes + (h->search_gbm ? 0 : bm_bytes));
+    if ((size_t)h->search_lds + static_lds > 48u * 1024u) {
+        const void* fn = h->search_gbm ? reinterpret_cast<const void*>(&dmpp::k_search<true>) : reinterpret_cast<const void*>(&dmpp::k_search<false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, h->search_lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->search_gbm) return fail(PP_ERR_HIP, "cannot reserve LDS for the search kernel");
+            h->search_gbm = true; h->search_lds = (int)nz_bytes;
+        }
     }
     if (h->search_gbm && !h->d_gbm) {
         int r = dmalloc(&h->d_gbm, (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
@@ -306,7 +314,7 @@ int pp_plan_tick(pp_handle h)
             Timed t(h, PP_K_SEARCH);
             (void)hipMemsetAsync(h->d_closed, 0, (size_t)n * ((size_t)c.grid_w * c.grid_h / 8), h->stream);   // the closed bit sets
             if (h->search_gbm)
-                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), 0, h->stream, c, n, h->caps.order_cap, h->d_in, h->d_grid,
+                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap, h->d_in, h->d_grid,
                                    h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, h->d_gbm);
             else
                 hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap,

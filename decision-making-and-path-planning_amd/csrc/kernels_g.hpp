@@ -141,7 +141,11 @@ __device__ __forceinline__ uint32_t pack_nz4(uint32_t x)   // 4 bytes -> 4 bits 
 //     complete behind it; direction + run length per closed cell go to HBM for the path, which is a
 //     handful of runs rather than hundreds of single cells.
 constexpr int kOpenCap = DMPP_OPEN_CAP;
-constexpr int kClosedTab = 2048, kClosedMax = 1536;     // LDS closed-set hash; beyond kClosedMax the HBM bit set answers
+constexpr int kClosedLog = 10, kClosedTab = 1 << kClosedLog, kClosedMax = 768;      // LDS closed-set hash; beyond kClosedMax the HBM bit set answers
+constexpr int kDiagK = DMPP_DIAG_JUMP;                  // cells a diagonal jump looks ahead
+constexpr int kDiagGroup = 2 * kDiagK;                  // lanes per diagonal jump: (cell, horizontal | vertical component)
+constexpr int kDiagPerRound = DMPP_WAVE / kDiagGroup;
+constexpr int kMaxDiag = 16;                            // diagonal jumps of a step: <= 4 nodes x 4 (start) / x 3
 
 // minimum over the 64 lanes, returned in every lane: DPP prefix-min inside each row of 16 lanes
 // (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row results to lane 63.
@@ -167,47 +171,75 @@ struct Bits {
     }
 };
 
-// One straight jump as a line scan.  A "view" is a bit matrix of NL lines x LW words: the row-major
-// bitmap for E/W (line = y, position along the line = x) or the transposed one for N/S (line = x,
-// position = y); the forced-neighbour test only needs the two neighbouring lines, so both axes share
-// the code.  run = cells travelled to the first stop, 0 = none.
-struct LineJob {
-    const uint32_t* base; int LW, NL;      // view
-    int line, pos, sgn;                    // start and direction along the line
-    int gline, gpos;                       // goal in this view
-    bool active;
+// One straight jump = one lane.  A "view" is a bit matrix of NL lines x LW words: the row-major bitmap for
+// E/W travel (line = y, position along the line = x) or the transposed one for N/S (line = x, position = y);
+// the forced-neighbour test only needs the two neighbouring lines, so both axes share the code.  `nz` holds
+// one bit per word of the view (word != 0), SW summary words per line: after the word the jump starts in, the
+// scan goes straight to the next word where the line or one of its two neighbours has any obstacle bit (or
+// to the goal's word) instead of walking the free words in between.
+struct View {
+    const uint32_t* base; const uint32_t* nz;
+    int LW, NL, SW;
 };
-__device__ __forceinline__ uint32_t view_word(const LineJob& J, int line, int w)
+__device__ __forceinline__ uint32_t view_word(const View& V, int line, int w)
 {
-    const bool ok = (unsigned)line < (unsigned)J.NL && (unsigned)w < (unsigned)J.LW;
-    const uint32_t v = J.base[ok ? line * J.LW + w : 0];
+    const bool ok = (unsigned)line < (unsigned)V.NL && (unsigned)w < (unsigned)V.LW;
+    const uint32_t v = V.base[ok ? line * V.LW + w : 0];
     return ok ? v : 0xFFFFFFFFu;
 }
-// stop mask of the 32-cell word `k` words ahead of the start (k = 0: only the cells strictly ahead)
-__device__ __forceinline__ uint32_t line_stop(const LineJob& J, int k, uint32_t& B0)
+__device__ __forceinline__ uint32_t view_nz(const View& V, int line, int sw)
 {
-    const int wp = J.pos >> 5, wi = wp + J.sgn * k, nwi = wi + J.sgn;
-    B0 = view_word(J, J.line, wi);
-    const uint32_t P = view_word(J, J.line + 1, wi), M = view_word(J, J.line - 1, wi);
-    const uint32_t Pw = view_word(J, J.line + 1, nwi), Mw = view_word(J, J.line - 1, nwi);
-    uint32_t Pn, Mn;
-    if (J.sgn > 0) { Pn = (P >> 1) | (Pw << 31); Mn = (M >> 1) | (Mw << 31); }
-    else           { Pn = (P << 1) | (Pw >> 31); Mn = (M << 1) | (Mw >> 31); }
-    uint32_t stop = B0 | (P & ~Pn) | (M & ~Mn);
-    if (J.gline == J.line && (J.gpos >> 5) == wi) stop |= 1u << (J.gpos & 31);
-    if (k == 0) {
-        const int bp = J.pos & 31;
-        if (J.sgn > 0) stop &= (bp == 31) ? 0u : ~((2u << bp) - 1u);
-        else           stop &= (1u << bp) - 1u;
-    }
-    return stop;
+    const bool ok = (unsigned)line < (unsigned)V.NL;
+    const uint32_t v = V.nz[ok ? line * V.SW + sw : 0];
+    return ok ? v : 0u;
 }
-__device__ __forceinline__ int line_run(const LineJob& J, int k, uint32_t w, uint32_t b0)
+// run = cells travelled from `pos` along `line` in direction sgn to the first stop (blocked | forced | goal);
+// 0 = none (the first stop is a wall or the edge of the grid).  Safe for starts outside the grid (returns 0).
+__device__ __forceinline__ int jump_lane(const View& V, bool active, int line, int pos, int sgn, int gline, int gpos)
 {
-    const int bit = J.sgn > 0 ? (__ffs((int)w) - 1) : (31 - __clz((int)w));
-    if ((b0 >> bit) & 1u) return 0;                    // the first stop is a wall
-    const int np = (((J.pos >> 5) + J.sgn * k) << 5) + bit;
-    return J.sgn > 0 ? np - J.pos : J.pos - np;
+    int run = 0;
+    bool go = active && (unsigned)line < (unsigned)V.NL && (unsigned)pos < (unsigned)(V.LW << 5);
+    int wi = pos >> 5;
+    bool first = true;
+    const int gw = (gline == line) ? (gpos >> 5) : -1;
+    for (int it = 0; it <= V.LW + 1; it++) {
+        if (!__ballot(go)) break;
+        if (go) {
+            const int nwi = wi + sgn;
+            const uint32_t B0 = view_word(V, line, wi);
+            const uint32_t P = view_word(V, line + 1, wi), M = view_word(V, line - 1, wi);
+            const uint32_t Pw = view_word(V, line + 1, nwi), Mw = view_word(V, line - 1, nwi);
+            // where to look next if this word holds no stop: summary words in travel order
+            int next = -1;
+            for (int k = 0; k < V.SW && next < 0; k++) {
+                const int sw = (wi >> 5) + sgn * k;
+                if ((unsigned)sw >= (unsigned)V.SW) break;
+                uint32_t m = view_nz(V, line, sw) | view_nz(V, line + 1, sw) | view_nz(V, line - 1, sw);
+                if (k == 0) m &= sgn > 0 ? ~((2u << (wi & 31)) - 1u) : ((1u << (wi & 31)) - 1u);
+                if (m) next = (sw << 5) + (sgn > 0 ? __ffs((int)m) - 1 : 31 - __clz((int)m));
+            }
+            if (gw >= 0 && (sgn > 0 ? (gw > wi && (next < 0 || gw < next)) : (gw < wi && (next < 0 || gw > next)))) next = gw;
+            uint32_t Pn, Mn;
+            if (sgn > 0) { Pn = (P >> 1) | (Pw << 31); Mn = (M >> 1) | (Mw << 31); }
+            else         { Pn = (P << 1) | (Pw >> 31); Mn = (M << 1) | (Mw >> 31); }
+            uint32_t stop = B0 | (P & ~Pn) | (M & ~Mn);
+            if (gw == wi) stop |= 1u << (gpos & 31);
+            if (first) {
+                const int bp = pos & 31;
+                if (sgn > 0) stop &= (bp == 31) ? 0u : ~((2u << bp) - 1u);
+                else         stop &= (1u << bp) - 1u;
+                first = false;
+            }
+            if (stop) {
+                const int bit = sgn > 0 ? (__ffs((int)stop) - 1) : (31 - __clz((int)stop));
+                if (!((B0 >> bit) & 1u)) { const int np = (wi << 5) + bit; run = sgn > 0 ? np - pos : pos - np; }
+                go = false;
+            } else if (next < 0) {
+                go = false;                                  // free all the way to the edge of the grid: no jump point
+            } else wi = next;
+        }
+    }
+    return run;
 }
 // Bit-matrix transpose of the row-major bitmap (H lines x WW words) into the column-major one
 // (W lines x HW words), 32x32 blocks in registers: each lane takes blocks lane, lane+64, ...
@@ -247,16 +279,20 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     __shared__ uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24
     __shared__ uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
     __shared__ uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
-    __shared__ int j_view[16], j_line[16], j_pos[16], j_sgn[16], j_run[16];   // the straight jumps of the current step
+    __shared__ int dc_owner[kMaxDiag], dc_run[kMaxDiag];                      // the diagonal jumps of the current step
     __shared__ uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
     const int lane = threadIdx.x;
     const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5;
-    // obstacle bits twice: row-major for E/W scans, column-major for N/S scans (N/32 words each)
-    uint32_t* bm = GBM ? gbitmaps + (size_t)scene * 2 * (N >> 5) : reinterpret_cast<uint32_t*>(smem_raw);
-    uint32_t* bmT = bm + (N >> 5);
     const int HW = H >> 5;
+    // dynamic LDS: the word summaries of both views (one bit per bitmap word), then - when they fit - the bitmaps
+    const int SWr = (WW + 31) >> 5, SWc = (HW + 31) >> 5;
+    uint32_t* nz_row = reinterpret_cast<uint32_t*>(smem_raw);
+    uint32_t* nz_col = nz_row + H * SWr;
+    // obstacle bits twice: row-major for E/W scans, column-major for N/S scans (N/32 words each)
+    uint32_t* bm = GBM ? gbitmaps + (size_t)scene * 2 * (N >> 5) : nz_col + W * SWc;
+    uint32_t* bmT = bm + (N >> 5);
     const SceneIn& si = in[scene];
     GridOut& go = gout[scene];
     const uint8_t* g = grid + (size_t)scene * N;
@@ -307,6 +343,16 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         wave_sync();
         transpose_bits(bm, bmT, W, H, lane);
         if (GBM) __threadfence();
+        wave_sync();
+        for (int i = lane; i < H * SWr + W * SWc; i += DMPP_WAVE) {        // word summaries of both views
+            const bool col = i >= H * SWr;
+            const int j = col ? i - H * SWr : i, SW = col ? SWc : SWr, LW = col ? HW : WW;
+            const uint32_t* src = (col ? bmT : bm) + (j / SW) * LW + ((j % SW) << 5);
+            const int nw = min(32, LW - ((j % SW) << 5));
+            uint32_t m = 0;
+            for (int b = 0; b < nw; b++) m |= (src[b] != 0u ? 1u : 0u) << b;
+            nz_row[i] = m;
+        }
         for (int i = lane; i < kClosedTab; i += DMPP_WAVE) c_tab[i] = 0;
         if (lane == 0) {
             o_ent[0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
@@ -317,9 +363,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         Bits<GBM> B{ bm, W, H, WW };     // single-cell tests of the diagonal steps
         int n_open = 1, live = 1, fmax = -1;
         n_push = 1;
-        // jobs of jw lanes (jw*32 cells must cover a whole line): 4 per pass at <= 512, 2 at <= 1024, 1 above
-        const int jw_log = (WW <= 16 && HW <= 16) ? 4 : ((WW <= 32 && HW <= 32) ? 5 : 6);
-        const int jw = 1 << jw_log, njpp = DMPP_WAVE >> jw_log;
+        const View Vrow{ bm, nz_row, WW, H, SWr }, Vcol{ bmT, nz_col, HW, W, SWc };
         // lane = node * 8 + s: the eight directions of each of the (<= 4) nodes of a step
         const int s = lane & 7;
         const int sdx = (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0);
@@ -401,7 +445,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 if (valid) {
                     atomicOr(&closed[cell >> 5], 1u << (cell & 31));          // the HBM set stays complete (fire and forget)
                     const uint32_t keyc = (uint32_t)cell + 1u;
-                    uint32_t hh = ((uint32_t)cell * 2654435761u) >> 21;
+                    uint32_t hh = ((uint32_t)cell * 2654435761u) >> (32 - kClosedLog);
                     for (int probe = 0; probe < kClosedTab; probe++) {
                         const uint32_t old = atomicCAS(&c_tab[hh], 0u, keyc);
                         if (old == 0u) break;                                 // inserted: was open
@@ -443,7 +487,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
             const int nx0 = __shfl(x, node, 64), ny0 = __shfl(y, node, 64), nd = __shfl(d, node, 64);
             const bool nvalid = lane < 32 && ((vm >> node) & 1u);
             const int gcur = f - hfun(nx0, ny0, gx, gy);
-            bool want_jump = false; int run = 0;
+            bool want_jump = false, want_diag = false; int run = 0;
             {
                 const int dd = nd & 7;
                 const int ddx = (dd == 0 || dd == 1 || dd == 7) ? 1 : ((dd >= 3 && dd <= 5) ? -1 : 0);
@@ -456,48 +500,55 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                 const int px = d_odd ? (sdx - ddx) / 2 : sdx - ddx, py = d_odd ? (sdy - ddy) / 2 : sdy - ddy;
                 const bool t_free = (plain || sided) && !B.blk(nx0 + sdx, ny0 + sdy);
                 const bool side_blk = sided && B.blk(nx0 + px, ny0 + py);
-                if ((plain && t_free) || (sided && side_blk && t_free)) run = 1;
+                want_diag = (plain && t_free) || (sided && side_blk && t_free);
             }
 #ifdef DMPP_DEBUG_SEARCH
             long long td = clock64(); t_cand += td - tc;
 #endif
-            // ---- every straight jump of the step is a job; jobs share passes, jw lanes each ----
-            const unsigned long long jm = __ballot(want_jump);
-            const int njobs = __popcll(jm);
-            int myjob = -1;
-            if (want_jump) {
-                myjob = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(jm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)jm, 0u));
+            // ---- straight jumps: the lane (node, s) that wants one scans for it itself ----
+            {
                 const bool horiz = s == 0 || s == 4;
-                j_view[myjob] = horiz ? 0 : 1;
-                j_line[myjob] = horiz ? ny0 : nx0;
-                j_pos[myjob] = horiz ? nx0 : ny0;
-                j_sgn[myjob] = (s == 0 || s == 2) ? 1 : -1;
+                const View V = horiz ? Vrow : Vcol;
+                const int r = jump_lane(V, want_jump, horiz ? ny0 : nx0, horiz ? nx0 : ny0, (s == 0 || s == 2) ? 1 : -1,
+                                        horiz ? gy : gx, horiz ? gx : gy);
+                if (want_jump) run = r;
             }
+            // ---- diagonal jumps: kDiagGroup lanes each = (cell 1..kDiagK along the diagonal) x (its horizontal |
+            //      vertical straight jump); the first cell that is blocked / the goal / forced / a jump-off point ends it ----
+            const unsigned dmask = (unsigned)__ballot(want_diag);
+            const int n_dc = __popc(dmask);
+            const int my_dc = __popc(dmask & ((1u << (lane & 31)) - 1u));
+            if (want_diag) dc_owner[my_dc] = lane;
             wave_order();
-            for (int p0 = 0; p0 < njobs; p0 += njpp) {
-                const int grp = lane >> jw_log, gl = lane & (jw - 1), job = p0 + grp;
-                LineJob J;
-                J.active = job < njobs;
-                const int jj = J.active ? job : 0;
-                const bool jv = j_view[jj] != 0;
-                J.base = jv ? bmT : bm; J.LW = jv ? HW : WW; J.NL = jv ? W : H;
-                J.line = j_line[jj]; J.pos = j_pos[jj]; J.sgn = j_sgn[jj];
-                J.gline = jv ? gx : gy; J.gpos = jv ? gy : gx;
-                uint32_t B0 = 0, stop = 0;
-                if (J.active) stop = line_stop(J, gl, B0);
-                const unsigned long long m = __ballot(stop != 0);
-                const unsigned long long gmask = jw == 64 ? m : ((m >> (grp << jw_log)) & ((1ull << jw) - 1ull));
-                // the lane holding the first stop of its group turns it into the run length itself
-                const int L = gmask ? __ffsll((long long)gmask) - 1 : -1;
-                if (J.active) {
-                    if (gl == L) j_run[job] = line_run(J, gl, stop, B0);
-                    else if (L < 0 && gl == 0) j_run[job] = 0;            // ran off the edge of the grid
+            for (int c0 = 0; c0 < n_dc; c0 += kDiagPerRound) {
+                const int grp = lane / kDiagGroup, t = lane % kDiagGroup, kk = t >> 1;
+                const bool hv = (t & 1) != 0;
+                const int dci = c0 + grp;
+                const bool act = dci < n_dc;
+                const int ol = dc_owner[act ? dci : 0];
+                const int ox = __shfl(nx0, ol, 64), oy = __shfl(ny0, ol, 64);
+                const int os = ol & 7;
+                const int odx = (os == 1 || os == 7) ? 1 : -1, ody = (os == 1 || os == 3) ? 1 : -1;
+                const int cx = ox + (kk + 1) * odx, cy = oy + (kk + 1) * ody;
+                const View V = hv ? Vcol : Vrow;
+                const int r = jump_lane(V, act, hv ? cx : cy, hv ? cy : cx, hv ? ody : odx, hv ? gx : gy, hv ? gy : gx);
+                bool cblk = false, cstop = false;
+                if (act && !hv) {
+                    cblk = B.blk(cx, cy);
+                    const bool forced = (B.blk(cx - odx, cy) && !B.blk(cx - odx, cy + ody)) || (B.blk(cx, cy - ody) && !B.blk(cx + odx, cy - ody));
+                    cstop = cblk || (cx == gx && cy == gy) || forced;
                 }
+                const unsigned long long sm = __ballot(act && (cstop || r > 0)), bk = __ballot(cblk);
+                const unsigned gs = (unsigned)(sm >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
+                const unsigned gb = (unsigned)(bk >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
+                int drun = kDiagK;
+                if (gs) { const int k1 = (__ffs((int)gs) - 1) >> 1; drun = ((gb >> (2 * k1)) & 1u) ? 0 : k1 + 1; }
+                if (act && t == 0) dc_run[dci] = drun;
                 wave_order();
             }
-            if (want_jump) run = j_run[myjob];
+            if (want_diag) run = dc_run[my_dc];
 #ifdef DMPP_DEBUG_SEARCH
-            long long te2 = clock64(); t_jump += te2 - td; c_jobs += njobs; c_pass += (njobs + njpp - 1) / njpp;
+            long long te2 = clock64(); t_jump += te2 - td; c_jobs += n_dc; c_pass += (n_dc + kDiagPerRound - 1) / kDiagPerRound;
 #endif
             // ---- push in batch order, then direction order ----
             const bool push = run > 0;

@@ -77,21 +77,27 @@ void orc_rasterise(const PlannerConfig* c, GlobalPoint2D origin, const ObPoint* 
 }
 
 /* ------------------------------------------------------------------------------ */
-/* G2: jump-point A* ("stepwise JPS": straight runs are jumped, diagonal moves are single steps that
- * go through the open list).  Optimal on the 8-connected grid with costs 10 / 14 and corner cutting
- * allowed; it expands only jump points and diagonal steps instead of every cell of the A* ellipse.
+/* G2: jump-point A* (JPS with straight jumps of any length and diagonal jumps bounded to
+ * DMPP_DIAG_JUMP cells per node).  Optimal on the 8-connected grid with costs 10 / 14 and corner
+ * cutting allowed; it expands only jump points (and one plain node every DMPP_DIAG_JUMP cells of a long
+ * diagonal) instead of every cell of the A* ellipse.
  *   grid    : blocked(x,y) = outside the grid or occupied; the start cell is always free.
  *   dirs    : d = 0..7 = E,NE,N,NW,W,SW,S,SE (even = straight, cost 10 per cell; odd = diagonal, 14).
  *   h       : octile, 10*max(|dx|,|dy|) + 4*min(|dx|,|dy|).
  *   jump(p,s), s straight: walk p+s, p+2s, ...; at each cell c: blocked -> none; c = goal -> c;
  *             c has a forced neighbour for travel s -> c, where forced means: a cell beside c
  *             (perpendicular to s) is blocked and the cell beside c+s on the same side is free.
+ *   jump(p,s), s diagonal = (sx,sy): walk c = p+s, p+2s, ... for at most DMPP_DIAG_JUMP cells; at each c:
+ *             blocked -> none; c = goal -> c; c has a forced neighbour for travel s -> c, where forced
+ *             means: (c-(sx,0) blocked and c+(-sx,sy) free) or (c-(0,sy) blocked and c+(sx,-sy) free);
+ *             jump(c,(sx,0)) or jump(c,(0,sy)) finds something -> c; after DMPP_DIAG_JUMP cells -> that cell
+ *             (a plain node: the diagonal goes on from there when it is expanded).
  *   successors of a node p closed with arriving direction d (8 = start), evaluated for s = 0..7 in turn:
- *             start      : s even -> jump(p,s);  s odd -> the cell p+s if free (one step);
- *             d straight : s = d -> jump(p,s);  s = d+-1 (the two diagonals next to d) -> the cell p+s,
+ *             start      : jump(p,s) for every s;
+ *             d straight : s = d -> jump(p,s);  s = d+-1 (the two diagonals next to d) -> jump(p,s),
  *                          only if forced: the cell beside p on that side is blocked and p+s is free;
- *             d diagonal : s = d+-1 (its two straight components) -> jump(p,s);  s = d -> p+s if free;
- *                          s = d+-2 -> p+s only if forced: the cell p + (s-d)/2 is blocked and p+s free.
+ *             d diagonal : s = d and s = d+-1 (its two straight components) -> jump(p,s);
+ *                          s = d+-2 -> jump(p,s) only if forced: the cell p + (s-d)/2 is blocked and p+s free.
  *   open set: a list in push order; an entry is (f, cell, arriving direction, run length); g is
  *             recovered as f - h(cell).
  *   step    : let fmin be the smallest f in the open set.  Up to DMPP_JPS_BATCH (4) entries with
@@ -146,6 +152,21 @@ static int jump_straight(const JGrid* G, int x, int y, int s, int gx, int gy)
             if ((jblk(G, x + 1, y) && !jblk(G, x + 1, y + dy)) || (jblk(G, x - 1, y) && !jblk(G, x - 1, y + dy))) return k;
         }
     }
+}
+
+/* diagonal jump from (x,y) in direction s (odd), at most DMPP_DIAG_JUMP cells; run length or 0 for none */
+static int jump_diagonal(const JGrid* G, int x, int y, int s, int gx, int gy)
+{
+    const int dx = DX[s], dy = DY[s];
+    const int sh = dx > 0 ? 0 : 4, sv = dy > 0 ? 2 : 6;          /* its straight components */
+    for (int k = 1; k <= DMPP_DIAG_JUMP; k++) {
+        x += dx; y += dy;
+        if (jblk(G, x, y)) return 0;
+        if (x == gx && y == gy) return k;
+        if ((jblk(G, x - dx, y) && !jblk(G, x - dx, y + dy)) || (jblk(G, x, y - dy) && !jblk(G, x + dx, y - dy))) return k;
+        if (jump_straight(G, x, y, sh, gx, gy) || jump_straight(G, x, y, sv, gx, gy)) return k;
+    }
+    return DMPP_DIAG_JUMP;
 }
 
 typedef struct OEnt { int f, cell, dir, run; } OEnt;
@@ -204,19 +225,19 @@ void orc_grid_search(const PlannerConfig* c, const uint8_t* grid, int start_cell
                 const int tx = x + DX[s], ty = y + DY[s];
                 if (d == 8) {
                     if ((s & 1) == 0) run = jump_straight(&G, x, y, s, gx, gy);
-                    else if (!jblk(&G, tx, ty)) run = 1;
+                    else run = jump_diagonal(&G, x, y, s, gx, gy);
                 } else if ((d & 1) == 0) {
                     if (s == d) run = jump_straight(&G, x, y, s, gx, gy);
                     else if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) {
                         const int px = DX[s] - DX[d], py = DY[s] - DY[d];          /* the side the diagonal leans to */
-                        if (jblk(&G, x + px, y + py) && !jblk(&G, tx, ty)) run = 1;
+                        if (jblk(&G, x + px, y + py) && !jblk(&G, tx, ty)) run = jump_diagonal(&G, x, y, s, gx, gy);
                     }
                 } else {
                     if (s == ((d + 1) & 7) || s == ((d + 7) & 7)) run = jump_straight(&G, x, y, s, gx, gy);
-                    else if (s == d) { if (!jblk(&G, tx, ty)) run = 1; }
+                    else if (s == d) run = jump_diagonal(&G, x, y, s, gx, gy);
                     else if (s == ((d + 2) & 7) || s == ((d + 6) & 7)) {
                         const int px = (DX[s] - DX[d]) / 2, py = (DY[s] - DY[d]) / 2;
-                        if (jblk(&G, x + px, y + py) && !jblk(&G, tx, ty)) run = 1;
+                        if (jblk(&G, x + px, y + py) && !jblk(&G, tx, ty)) run = jump_diagonal(&G, x, y, s, gx, gy);
                     }
                 }
                 if (!run) continue;

@@ -158,6 +158,39 @@ def _mix64(v):
     return z ^ (z >> 31)
 
 
+def test_grid_search_optimal_on_random_mazes(dm, oracle):
+    """Jump points, forced neighbours and bounded diagonal jumps on cluttered grids: cost equals Dijkstra's,
+    NO_PATH exactly when Dijkstra finds none."""
+    cfg = dm.default_config(64)
+    rng = np.random.default_rng(21)
+    n_found = n_none = 0
+    for trial in range(250):
+        dens = float(rng.choice([0.05, 0.15, 0.25, 0.35, 0.45, 0.55, 0.62]))
+        grid = (rng.random((64, 64)) < dens).astype(np.uint8)
+        if trial % 5 == 0:                       # walls with gaps: long corridors, forced neighbours at the gaps
+            grid[:] = 0
+            for x in range(8, 64, 8):
+                grid[:, x] = 1
+                grid[rng.integers(0, 64, 3), x] = 0
+        st, go = int(rng.integers(0, 64 * 64)), int(rng.integers(0, 64 * 64))
+        grid.reshape(-1)[go] = 0
+        out, order, path = oracle.grid_search(cfg, grid, st, go, order_cap=64 * 64)
+        g2 = grid.copy()
+        g2.reshape(-1)[st] = 0
+        ref = _dijkstra(g2, st, go)
+        if ref is None:
+            assert int(out["status"][0]) == dm.G_NO_PATH, trial
+            n_none += 1
+            continue
+        n_found += 1
+        assert int(out["status"][0]) == dm.G_FOUND and int(out["path_cost"][0]) == ref, (trial, dens)
+        assert path[0] == st and path[-1] == go
+        steps = np.diff(np.stack([path % 64, path // 64]), axis=1)
+        assert (np.abs(steps) <= 1).all() and not g2.reshape(-1)[path].any()               # 8-connected, through free cells
+        assert int((np.abs(steps).sum(axis=0) == 2).sum()) * 14 + int((np.abs(steps).sum(axis=0) == 1).sum()) * 10 == ref
+    assert n_found > 120 and n_none > 20
+
+
 def test_scoring_prefers_clear_low_curvature_candidates(dm, oracle, cfg):
     sc = dm.gen_scenes(cfg, 70, 16, 8, junction_every=0)
     st = sc["state"].copy()

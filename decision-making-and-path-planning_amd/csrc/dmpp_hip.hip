@@ -117,7 +117,7 @@ int setup_grid_launch(pp_planner* h)
     if (!c.grid_stage) return PP_OK;
     const size_t N = (size_t)c.grid_w * c.grid_h;
     // rasterise: bands of <= 65536 cells (8 KiB of LDS bits), whole rows
-    int band = 65536 / c.grid_w; if (band < 1) band = 1; if (band > c.grid_h) band = c.grid_h;
+    int band = (65536 / c.grid_w) / 32 * 32; if (band < 32) band = 32; if (band > c.grid_h) band = c.grid_h;   // whole 32-row words
     h->raster_band_rows = band;
     // search: word summaries of both bitmap views always in LDS; the bitmaps too when they fit, else in HBM
     const size_t bm_bytes = 2 * (N / 8);              // row-major + column-major obstacle bits
@@ -144,7 +144,7 @@ int setup_grid_launch(pp_planner* h)
             h->search_gbm = true; h->search_lds = (int)nz_bytes;
         }
     }
-    if (h->search_gbm && !h->d_gbm) {
+    if (!h->d_gbm) {          // bit-packed occupancy, row- and column-major: written by k_rasterise, read by k_search
         int r = dmalloc(&h->d_gbm, (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
         if (r) return r;
     }
@@ -306,19 +306,19 @@ int pp_plan_tick(pp_handle h)
         {
             Timed t(h, PP_K_RASTERISE);
             const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
-            const size_t lds = (size_t)h->raster_band_rows * c.grid_w / 8;
+            const size_t lds = 2 * ((size_t)h->raster_band_rows * c.grid_w / 8);      // the band row-major and column-major
             hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, h->stream, c, n, h->raster_band_rows,
-                               h->d_in, h->d_obs_now, h->d_grid);
+                               h->d_in, h->d_obs_now, h->d_grid, h->d_gbm);
         }
         {
             Timed t(h, PP_K_SEARCH);
             (void)hipMemsetAsync(h->d_closed, 0, (size_t)n * ((size_t)c.grid_w * c.grid_h / 8), h->stream);   // the closed bit sets
             if (h->search_gbm)
-                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap, h->d_in, h->d_grid,
+                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap, h->d_in,
                                    h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, h->d_gbm);
             else
                 hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap,
-                                   h->d_in, h->d_grid, h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, (uint32_t*)nullptr);
+                                   h->d_in, h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, h->d_gbm);
         }
         {
             Timed t(h, PP_K_SCORE);

@@ -39,19 +39,21 @@ constexpr int kRasterBlock = 256;
 
 __global__ void __launch_bounds__(kRasterBlock)
 k_rasterise(PlannerConfig c, int n_scenes, int band_rows, const SceneIn* __restrict__ in,
-            const ObPoint* __restrict__ obs_now, uint8_t* __restrict__ grid)
+            const ObPoint* __restrict__ obs_now, uint8_t* __restrict__ grid, uint32_t* __restrict__ gbits)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    uint32_t* bits = reinterpret_cast<uint32_t*>(smem_raw);          // band_rows*W/32 words
     const int scene = blockIdx.x, band = blockIdx.y;
     if (scene >= n_scenes) return;
-    const int W = c.grid_w, H = c.grid_h;
-    const int row0 = band * band_rows;
+    const int W = c.grid_w, H = c.grid_h, WW = W >> 5, HW = H >> 5;
+    const int row0 = band * band_rows;                               // band_rows is a multiple of 32
     const int rows = min(band_rows, H - row0);
     if (rows <= 0) return;
     const int words = (rows * W) >> 5;
+    const int bw = rows >> 5;                                        // words per column inside this band
+    uint32_t* bits = reinterpret_cast<uint32_t*>(smem_raw);          // row-major band: rows x WW words
+    uint32_t* bitsT = bits + ((band_rows * W) >> 5);                 // column-major band: W x bw words
     const int tid = threadIdx.x;
-    for (int w = tid; w < words; w += kRasterBlock) bits[w] = 0;
+    for (int w = tid; w < words; w += kRasterBlock) { bits[w] = 0; bitsT[w] = 0; }
     __syncthreads();
     const SceneIn& si = in[scene];
     const double ox = si.grid_origin.x, oy = si.grid_origin.y;
@@ -84,22 +86,23 @@ k_rasterise(PlannerConfig c, int n_scenes, int band_rows, const SceneIn* __restr
         const int nhit = s_cnt;
         for (int k = 0; k < nhit; k++) {
             const int ix0 = s_box[k][0], iy0 = s_box[k][2];
-            const int bw = s_box[k][1] - ix0 + 1, bh = s_box[k][3] - iy0 + 1;
+            const int bwid = s_box[k][1] - ix0 + 1, bh = s_box[k][3] - iy0 + 1;
             const double cxo = s_par[k][0], cyo = s_par[k][1], R2 = s_par[k][2];
-            for (int t = tid; t < bw * bh; t += kRasterBlock) {
-                const int iy = iy0 + t / bw, ix = ix0 + t % bw;
+            for (int t = tid; t < bwid * bh; t += kRasterBlock) {
+                const int iy = iy0 + t / bwid, ix = ix0 + t % bwid;
                 const double cx = ox + ((double)ix + 0.5) * c.cell, cy = oy + ((double)iy + 0.5) * c.cell;
                 const double dx = cx - cxo, dy = cy - cyo;
                 if (dx * dx + dy * dy <= R2) {
-                    const int b = (iy - row0) * W + ix;
+                    const int r = iy - row0, b = r * W + ix;
                     atomicOr(&bits[b >> 5], 1u << (b & 31));
+                    atomicOr(&bitsT[ix * bw + (r >> 5)], 1u << (r & 31));     // the same cell in the column-major copy
                 }
             }
         }
         __syncthreads();
     }
     __syncthreads();
-    // expand 16 bits -> 16 bytes per lane per store (uint4), fully coalesced
+    // (1) the occupancy grid proper: expand 16 bits -> 16 bytes per lane per store (uint4), fully coalesced
     uint4* out = reinterpret_cast<uint4*>(grid + ((size_t)scene * H + row0) * W);
     const int chunks = (rows * W) >> 4;
     for (int k = tid; k < chunks; k += kRasterBlock) {
@@ -112,6 +115,11 @@ k_rasterise(PlannerConfig c, int n_scenes, int band_rows, const SceneIn* __restr
         v.w = (((h16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u;
         out[k] = v;
     }
+    // (2) its bit-packed forms for the search: row-major (H x WW words) then column-major (W x HW words)
+    uint32_t* brow = gbits + (size_t)scene * 2 * ((size_t)(W * H) >> 5);
+    uint32_t* bcol = brow + ((size_t)(W * H) >> 5);
+    for (int w = tid; w < words; w += kRasterBlock) brow[row0 * WW + w] = bits[w];
+    for (int w = tid; w < words; w += kRasterBlock) bcol[(w / bw) * HW + (row0 >> 5) + (w % bw)] = bitsT[w];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -119,11 +127,6 @@ __device__ __forceinline__ int hfun(int x, int y, int gx, int gy)
 {
     int dx = abs(x - gx), dy = abs(y - gy);
     return 10 * max(dx, dy) + 4 * min(dx, dy);
-}
-__device__ __forceinline__ uint32_t pack_nz4(uint32_t x)   // 4 bytes -> 4 bits (bit k = byte k != 0)
-{
-    uint32_t nz = ((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u) >> 7;
-    return (nz * 0x01020408u) >> 24;
 }
 
 // G2: jump-point A* (specification: oracle/dmpp_grid_oracle.c).  ONE WAVE per scene.
@@ -195,83 +198,55 @@ __device__ __forceinline__ uint32_t view_nz(const View& V, int line, int sw)
 }
 // run = cells travelled from `pos` along `line` in direction sgn to the first stop (blocked | forced | goal);
 // 0 = none (the first stop is a wall or the edge of the grid).  Safe for starts outside the grid (returns 0).
-__device__ __forceinline__ int jump_lane(const View& V, bool active, int line, int pos, int sgn, int gline, int gpos)
+// Only words whose summary bit is set in the line or one of its two neighbours (or that hold the goal) can
+// contain a stop: those candidate words are visited in travel order, nothing else is read.  LW <= 64.
+__device__ __forceinline__ int jump_lane(const View& V, bool active, int line, int pos, int sgn, int gline, int gpos, int* iters = nullptr)
 {
     int run = 0;
     bool go = active && (unsigned)line < (unsigned)V.NL && (unsigned)pos < (unsigned)(V.LW << 5);
-    int wi = pos >> 5;
-    bool first = true;
-    const int gw = (gline == line) ? (gpos >> 5) : -1;
-    for (int it = 0; it <= V.LW + 1; it++) {
+    const int w0 = pos >> 5;
+    unsigned long long cand = 0;
+    if (go) {
+        uint32_t lo = view_nz(V, line, 0) | view_nz(V, line + 1, 0) | view_nz(V, line - 1, 0), hi = 0;
+        if (V.SW > 1) hi = view_nz(V, line, 1) | view_nz(V, line + 1, 1) | view_nz(V, line - 1, 1);
+        cand = ((unsigned long long)hi << 32) | lo;
+        if (gline == line) cand |= 1ull << (gpos >> 5);
+        cand &= sgn > 0 ? ~((1ull << w0) - 1ull) : ((2ull << w0) - 1ull);     // the start word and everything ahead of it
+        go = cand != 0;
+    }
+    for (int it = 0; it <= V.LW; it++) {
         if (!__ballot(go)) break;
+        if (iters) ++*iters;
         if (go) {
+            const int wi = sgn > 0 ? __ffsll((long long)cand) - 1 : 63 - __clzll((long long)cand);
+            cand &= ~(1ull << wi);
             const int nwi = wi + sgn;
             const uint32_t B0 = view_word(V, line, wi);
             const uint32_t P = view_word(V, line + 1, wi), M = view_word(V, line - 1, wi);
             const uint32_t Pw = view_word(V, line + 1, nwi), Mw = view_word(V, line - 1, nwi);
-            // where to look next if this word holds no stop: summary words in travel order
-            int next = -1;
-            for (int k = 0; k < V.SW && next < 0; k++) {
-                const int sw = (wi >> 5) + sgn * k;
-                if ((unsigned)sw >= (unsigned)V.SW) break;
-                uint32_t m = view_nz(V, line, sw) | view_nz(V, line + 1, sw) | view_nz(V, line - 1, sw);
-                if (k == 0) m &= sgn > 0 ? ~((2u << (wi & 31)) - 1u) : ((1u << (wi & 31)) - 1u);
-                if (m) next = (sw << 5) + (sgn > 0 ? __ffs((int)m) - 1 : 31 - __clz((int)m));
-            }
-            if (gw >= 0 && (sgn > 0 ? (gw > wi && (next < 0 || gw < next)) : (gw < wi && (next < 0 || gw > next)))) next = gw;
             uint32_t Pn, Mn;
             if (sgn > 0) { Pn = (P >> 1) | (Pw << 31); Mn = (M >> 1) | (Mw << 31); }
             else         { Pn = (P << 1) | (Pw >> 31); Mn = (M << 1) | (Mw >> 31); }
             uint32_t stop = B0 | (P & ~Pn) | (M & ~Mn);
-            if (gw == wi) stop |= 1u << (gpos & 31);
-            if (first) {
+            if (gline == line && (gpos >> 5) == wi) stop |= 1u << (gpos & 31);
+            if (wi == w0) {                                  // only the cells strictly ahead of the start
                 const int bp = pos & 31;
                 if (sgn > 0) stop &= (bp == 31) ? 0u : ~((2u << bp) - 1u);
                 else         stop &= (1u << bp) - 1u;
-                first = false;
             }
             if (stop) {
                 const int bit = sgn > 0 ? (__ffs((int)stop) - 1) : (31 - __clz((int)stop));
                 if (!((B0 >> bit) & 1u)) { const int np = (wi << 5) + bit; run = sgn > 0 ? np - pos : pos - np; }
                 go = false;
-            } else if (next < 0) {
-                go = false;                                  // free all the way to the edge of the grid: no jump point
-            } else wi = next;
+            } else if (cand == 0) go = false;                // free all the way to the edge of the grid: no jump point
         }
     }
     return run;
 }
-// Bit-matrix transpose of the row-major bitmap (H lines x WW words) into the column-major one
-// (W lines x HW words), 32x32 blocks in registers: each lane takes blocks lane, lane+64, ...
-__device__ __forceinline__ void transpose_bits(const uint32_t* src, uint32_t* dst, int W, int H, int lane)
-{
-    const int WW = W >> 5, HW = H >> 5;
-    for (int blk = lane; blk < WW * HW; blk += DMPP_WAVE) {
-        const int bx = blk % WW, by = blk / WW;
-        uint32_t a[32];
-#pragma unroll
-        for (int i = 0; i < 32; i++) a[i] = src[(by * 32 + i) * WW + bx];
-        // a[i] bit j = cell (32 bx + j, 32 by + i)  ->  t[j] bit i
-#pragma unroll
-        for (int sft = 16; sft >= 1; sft >>= 1) {
-            const uint32_t mask = sft == 16 ? 0x0000FFFFu : sft == 8 ? 0x00FF00FFu : sft == 4 ? 0x0F0F0F0Fu : sft == 2 ? 0x33333333u : 0x55555555u;
-#pragma unroll
-            for (int i = 0; i < 32; i++) {
-                if ((i & sft) == 0) {
-                    const uint32_t lo = a[i], hi = a[i + sft];
-                    a[i] = (lo & mask) | ((hi & mask) << sft);
-                    a[i + sft] = ((lo >> sft) & mask) | (hi & ~mask);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 32; j++) dst[(bx * 32 + j) * HW + by] = a[j];
-    }
-}
 
 template <bool GBM>
 __global__ void __launch_bounds__(DMPP_WAVE)
-k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict__ in, const uint8_t* __restrict__ grid,
+k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict__ in,
          uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
          int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps)
 {
@@ -280,9 +255,13 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     __shared__ uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
     __shared__ uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
     __shared__ int dc_owner[kMaxDiag], dc_run[kMaxDiag];                      // the diagonal jumps of the current step
+    __shared__ uint32_t sj_job[kDiagGroup]; __shared__ int sj_run[kDiagGroup]; // its straight jumps (<= 8)
     __shared__ uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
+#ifdef DMPP_DEBUG_SEARCH
+    const long long t_entry = clock64(); long long t_loop = t_entry;
+#endif
     const int lane = threadIdx.x;
     const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5;
     const int HW = H >> 5;
@@ -295,36 +274,29 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     uint32_t* bmT = bm + (N >> 5);
     const SceneIn& si = in[scene];
     GridOut& go = gout[scene];
-    const uint8_t* g = grid + (size_t)scene * N;
     uint32_t* closed = gclosed + (size_t)scene * (N >> 5);        // zeroed by the host before the launch
     uint16_t* pin = pinfo + (size_t)scene * N;
     int32_t* order = orders ? orders + (size_t)scene * order_cap : nullptr;
     int32_t* path = paths + (size_t)scene * c.max_path;
 
-    // ---- occupancy bytes -> bits: lane i of a load covers bytes [16 i, 16 i + 16) of a 1-KiB span
-    //      (fully coalesced), packs them to 16 bits and stores one 16-bit word ----
-    {
-        const uint4* g4 = reinterpret_cast<const uint4*>(g);
-        uint16_t* bm16 = reinterpret_cast<uint16_t*>(bm);
-        const int chunks = N >> 4;
-        constexpr int U = 8;                                   // 8 KiB in flight per wave
+    // ---- the bit-packed occupancy grid (both orientations, written by k_rasterise) -> LDS, 16 B per lane ----
+    if (!GBM) {
+        const uint4* src4 = reinterpret_cast<const uint4*>(gbitmaps + (size_t)scene * 2 * (N >> 5));
+        uint4* dst4 = reinterpret_cast<uint4*>(bm);
+        const int chunks = (2 * (N >> 5)) >> 2;
+        constexpr int U = 16;                                  // 16 KiB in flight per wave
         for (int c0 = 0; c0 < chunks; c0 += DMPP_WAVE * U) {
             uint4 a[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int k = c0 + u * DMPP_WAVE + lane;
-                if (k < chunks) a[u] = g4[k];
-            }
+            for (int u = 0; u < U; u++) a[u] = src4[min(c0 + u * DMPP_WAVE + lane, chunks - 1)];     // branch-free: all 16 loads in flight
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int k = c0 + u * DMPP_WAVE + lane;
-                if (k < chunks)
-                    bm16[k] = (uint16_t)(pack_nz4(a[u].x) | (pack_nz4(a[u].y) << 4) | (pack_nz4(a[u].z) << 8) | (pack_nz4(a[u].w) << 12));
-            }
+            for (int u = 0; u < U; u++) { const int k = c0 + u * DMPP_WAVE + lane; if (k < chunks) dst4[k] = a[u]; }
         }
     }
-    if (GBM) __threadfence();
     wave_sync();
+#ifdef DMPP_DEBUG_SEARCH
+    const long long t_pack = clock64(); long long t_tr = t_pack, t_nz = t_pack;
+#endif
 
     const int start = cell_of(c, si.grid_origin, si.loc.globalpoint.x, si.loc.globalpoint.y);
     const int goal = cell_of(c, si.grid_origin, si.goal.x, si.goal.y);
@@ -339,20 +311,53 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     if ((bm[goal >> 5] >> (goal & 31)) & 1u) {
         status = DMPP_G_GOAL_BLOCKED;
     } else {
-        if (lane == 0) bm[start >> 5] &= ~(1u << (start & 31));            // the vehicle is where it is
-        wave_sync();
-        transpose_bits(bm, bmT, W, H, lane);
+        if (lane == 0) {                                                    // the vehicle is where it is
+            const int sx = start % W, sy = start / W;
+            bm[start >> 5] &= ~(1u << (start & 31));
+            bmT[sx * HW + (sy >> 5)] &= ~(1u << (sy & 31));
+        }
         if (GBM) __threadfence();
         wave_sync();
-        for (int i = lane; i < H * SWr + W * SWc; i += DMPP_WAVE) {        // word summaries of both views
-            const bool col = i >= H * SWr;
-            const int j = col ? i - H * SWr : i, SW = col ? SWc : SWr, LW = col ? HW : WW;
-            const uint32_t* src = (col ? bmT : bm) + (j / SW) * LW + ((j % SW) << 5);
-            const int nw = min(32, LW - ((j % SW) << 5));
-            uint32_t m = 0;
-            for (int b = 0; b < nw; b++) m |= (src[b] != 0u ? 1u : 0u) << b;
-            nz_row[i] = m;
+#ifdef DMPP_DEBUG_SEARCH
+        t_tr = clock64();
+#endif
+        // word summaries of both views (bit = word != 0): 64 consecutive words per ballot when a line is a
+        // power-of-two number of words, else word by word
+        for (int v = 0; v < 2; v++) {
+            const uint32_t* src = v ? bmT : bm;
+            uint32_t* nz = v ? nz_col : nz_row;
+            const int LW = v ? HW : WW, NL = v ? W : H, SW = v ? SWc : SWr, total = NL * LW;
+            if ((LW & (LW - 1)) == 0 && LW <= 64) {
+                const int lw_log = 31 - __clz(LW);
+                const int piece = min(LW, 32), npiece = DMPP_WAVE / piece;
+                const unsigned long long pmask = piece == 32 ? 0xFFFFFFFFull : ((1ull << piece) - 1ull);
+                const int psh = (lane < npiece ? lane : 0) * piece;
+                constexpr int UN = 8;
+                for (int c0 = 0; c0 < total; c0 += DMPP_WAVE * UN) {
+                    uint32_t wv[UN];
+#pragma unroll
+                    for (int u = 0; u < UN; u++) wv[u] = src[min(c0 + u * DMPP_WAVE + lane, total - 1)];
+#pragma unroll
+                    for (int u = 0; u < UN; u++) {
+                        const int cu = c0 + u * DMPP_WAVE;
+                        const unsigned long long b = __ballot(wv[u] != 0u && cu + lane < total);
+                        const int w = cu + lane * piece;
+                        if (lane < npiece && w < total) nz[(w >> lw_log) * SW + ((w & (LW - 1)) >> 5)] = (uint32_t)((b >> psh) & pmask);
+                    }
+                }
+            } else {
+                for (int i = lane; i < NL * SW; i += DMPP_WAVE) {
+                    const uint32_t* p = src + (i / SW) * LW + ((i % SW) << 5);
+                    const int nw = min(32, LW - ((i % SW) << 5));
+                    uint32_t m = 0;
+                    for (int b = 0; b < nw; b++) m |= (p[b] != 0u ? 1u : 0u) << b;
+                    nz[i] = m;
+                }
+            }
         }
+#ifdef DMPP_DEBUG_SEARCH
+        t_nz = clock64();
+#endif
         for (int i = lane; i < kClosedTab; i += DMPP_WAVE) c_tab[i] = 0;
         if (lane == 0) {
             o_ent[0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
@@ -369,10 +374,13 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         const int sdx = (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0);
         const int sdy = (s >= 1 && s <= 3) ? 1 : ((s >= 5) ? -1 : 0);
         long long guard = 16ll * N + 1024;                 // every iteration pops an entry; entries <= 8 per closed cell
+#ifdef DMPP_DEBUG_SEARCH
+        t_loop = clock64();
+#endif
         while (status < 0) {
             if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
 #ifdef DMPP_DEBUG_SEARCH
-            c_iter++; long long ta = clock64(); c_scan += (n_open + 63) / 64;
+            c_iter++; long long ta = clock64();
 #endif
             if (live == 0) { status = DMPP_G_NO_PATH; break; }
             // ---- pop: up to 4 entries of the smallest f, the latest pushes first ----
@@ -505,50 +513,61 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
 #ifdef DMPP_DEBUG_SEARCH
             long long td = clock64(); t_cand += td - tc;
 #endif
-            // ---- straight jumps: the lane (node, s) that wants one scans for it itself ----
-            {
+            // ---- jumps.  Every straight scan is one lane (jump_lane).  The straight successors of the batch (<= 8; 4 for
+            //      the start node) and the diagonal ones share the wave: a diagonal jump takes kDiagGroup lanes =
+            //      (cell 1..kDiagK along the diagonal) x (its horizontal | vertical straight jump), and the first cell
+            //      that is blocked / the goal / forced / a jump-off point ends it.  Round 0 = three diagonal jumps on
+            //      lanes 0..47 + the straight ones on lanes 48..63; further rounds (rare) = four diagonal jumps each ----
+            const unsigned smask = (unsigned)__ballot(want_jump), dmask = (unsigned)__ballot(want_diag);
+            const int n_sj = __popc(smask), n_dc = __popc(dmask);
+            const int my_sj = __popc(smask & ((1u << (lane & 31)) - 1u)), my_dc = __popc(dmask & ((1u << (lane & 31)) - 1u));
+            if (want_jump) {
                 const bool horiz = s == 0 || s == 4;
-                const View V = horiz ? Vrow : Vcol;
-                const int r = jump_lane(V, want_jump, horiz ? ny0 : nx0, horiz ? nx0 : ny0, (s == 0 || s == 2) ? 1 : -1,
-                                        horiz ? gy : gx, horiz ? gx : gy);
-                if (want_jump) run = r;
+                // view | sgn | line | pos, 12 bits each for line and pos (always inside the grid here)
+                sj_job[my_sj] = (horiz ? 0u : 1u) | ((s == 0 || s == 2) ? 2u : 0u) | ((uint32_t)(horiz ? ny0 : nx0) << 2) | ((uint32_t)(horiz ? nx0 : ny0) << 14);
             }
-            // ---- diagonal jumps: kDiagGroup lanes each = (cell 1..kDiagK along the diagonal) x (its horizontal |
-            //      vertical straight jump); the first cell that is blocked / the goal / forced / a jump-off point ends it ----
-            const unsigned dmask = (unsigned)__ballot(want_diag);
-            const int n_dc = __popc(dmask);
-            const int my_dc = __popc(dmask & ((1u << (lane & 31)) - 1u));
             if (want_diag) dc_owner[my_dc] = lane;
             wave_order();
-            for (int c0 = 0; c0 < n_dc; c0 += kDiagPerRound) {
+            const int n_rounds_j = (n_sj | n_dc) ? 1 + (max(n_dc - 3, 0) + kDiagPerRound - 1) / kDiagPerRound : 0;
+            for (int rnd = 0; rnd < n_rounds_j; rnd++) {
                 const int grp = lane / kDiagGroup, t = lane % kDiagGroup, kk = t >> 1;
-                const bool hv = (t & 1) != 0;
-                const int dci = c0 + grp;
-                const bool act = dci < n_dc;
-                const int ol = dc_owner[act ? dci : 0];
+                const bool is_s = rnd == 0 && grp == kDiagPerRound - 1;            // the straight-jump lanes of round 0
+                const int dci = rnd == 0 ? grp : (kDiagPerRound - 1) + (rnd - 1) * kDiagPerRound + grp;
+                const bool dact = !is_s && dci < n_dc, sact = is_s && t < n_sj;
+                const int ol = dc_owner[dact ? dci : 0];
                 const int ox = __shfl(nx0, ol, 64), oy = __shfl(ny0, ol, 64);
                 const int os = ol & 7;
                 const int odx = (os == 1 || os == 7) ? 1 : -1, ody = (os == 1 || os == 3) ? 1 : -1;
                 const int cx = ox + (kk + 1) * odx, cy = oy + (kk + 1) * ody;
+                const uint32_t sj = sj_job[sact ? t : 0];
+                bool hv = (t & 1) != 0;                                            // vertical scan?
+                int jl = hv ? cx : cy, jp = hv ? cy : cx, jsg = hv ? ody : odx;
+                if (is_s) { hv = (sj & 1u) != 0; jsg = (sj & 2u) ? 1 : -1; jl = (int)((sj >> 2) & 0xFFFu); jp = (int)(sj >> 14); }
                 const View V = hv ? Vcol : Vrow;
-                const int r = jump_lane(V, act, hv ? cx : cy, hv ? cy : cx, hv ? ody : odx, hv ? gx : gy, hv ? gy : gx);
+                #ifdef DMPP_DEBUG_SEARCH
+                const int r = jump_lane(V, dact || sact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx, &c_scan);
+#else
+                const int r = jump_lane(V, dact || sact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx);
+#endif
+                if (sact) sj_run[t] = r;
                 bool cblk = false, cstop = false;
-                if (act && !hv) {
+                if (dact && (t & 1) == 0) {
                     cblk = B.blk(cx, cy);
                     const bool forced = (B.blk(cx - odx, cy) && !B.blk(cx - odx, cy + ody)) || (B.blk(cx, cy - ody) && !B.blk(cx + odx, cy - ody));
                     cstop = cblk || (cx == gx && cy == gy) || forced;
                 }
-                const unsigned long long sm = __ballot(act && (cstop || r > 0)), bk = __ballot(cblk);
+                const unsigned long long sm = __ballot(dact && (cstop || r > 0)), bk = __ballot(cblk);
                 const unsigned gs = (unsigned)(sm >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
                 const unsigned gb = (unsigned)(bk >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
                 int drun = kDiagK;
                 if (gs) { const int k1 = (__ffs((int)gs) - 1) >> 1; drun = ((gb >> (2 * k1)) & 1u) ? 0 : k1 + 1; }
-                if (act && t == 0) dc_run[dci] = drun;
+                if (dact && t == 0) dc_run[dci] = drun;
                 wave_order();
             }
+            if (want_jump) run = sj_run[my_sj];
             if (want_diag) run = dc_run[my_dc];
 #ifdef DMPP_DEBUG_SEARCH
-            long long te2 = clock64(); t_jump += te2 - td; c_jobs += n_dc; c_pass += (n_dc + kDiagPerRound - 1) / kDiagPerRound;
+            long long te2 = clock64(); t_jump += te2 - td; c_jobs += n_dc; c_pass += n_rounds_j;
 #endif
             // ---- push in batch order, then direction order ----
             const bool push = run > 0;
@@ -656,8 +675,8 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         }
     }
 #ifdef DMPP_DEBUG_SEARCH
-    if (lane == 0) { long long te = clock64(); int32_t* dbg = path + c.max_path - 16; dbg[0] = c_iter; dbg[1] = c_nt; dbg[2] = c_jobs; dbg[3] = c_pass; dbg[4] = c_scan;
-        dbg[5] = (int)(t_pop >> 4); dbg[6] = (int)(t_closed >> 4); dbg[7] = (int)(t_cand >> 4); dbg[8] = (int)(t_jump >> 4); dbg[9] = (int)(t_push >> 4); dbg[10] = (int)((te - t_done) >> 4); dbg[11] = (int)((te - t0) >> 4); }
+    if (lane == 0) { long long te = clock64(); int32_t* dbg = path + c.max_path - 16; dbg[0] = c_iter; dbg[1] = c_scan; dbg[2] = c_jobs; dbg[3] = c_pass; dbg[4] = c_scan;
+        dbg[5] = (int)(t_pop >> 4); dbg[6] = (int)(t_closed >> 4); dbg[7] = (int)(t_cand >> 4); dbg[8] = (int)(t_jump >> 4); dbg[9] = (int)(t_push >> 4); dbg[10] = (int)((te - t_done) >> 4); dbg[11] = (int)((te - t0) >> 4); dbg[12] = (int)((t_loop - t_entry) >> 4); dbg[13] = (int)((te - t_entry) >> 4); dbg[14] = (int)((t_pack - t_entry) >> 4); dbg[15] = (int)((t_tr - t_pack) >> 4); dbg[4] = (int)((t_nz - t_tr) >> 4); }
 #endif
     if (lane == 0) {
         go.order_digest = digest; go.status = status; go.n_expanded = n_exp; go.n_pushed = n_push; go.n_rounds = n_rounds;

@@ -257,6 +257,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     __shared__ int dc_owner[kMaxDiag], dc_run[kMaxDiag];                      // the diagonal jumps of the current step
     __shared__ uint32_t sj_job[kDiagGroup]; __shared__ int sj_run[kDiagGroup]; // its straight jumps (<= 8)
     __shared__ uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
+    __shared__ uint16_t c_info[kClosedTab];    // arriving direction | run length << 4 of the cell in the same slot
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
 #ifdef DMPP_DEBUG_SEARCH
@@ -284,14 +285,14 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         const uint4* src4 = reinterpret_cast<const uint4*>(gbitmaps + (size_t)scene * 2 * (N >> 5));
         uint4* dst4 = reinterpret_cast<uint4*>(bm);
         const int chunks = (2 * (N >> 5)) >> 2;
-        constexpr int U = 16;                                  // 16 KiB in flight per wave
-        for (int c0 = 0; c0 < chunks; c0 += DMPP_WAVE * U) {
-            uint4 a[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) a[u] = src4[min(c0 + u * DMPP_WAVE + lane, chunks - 1)];     // branch-free: all 16 loads in flight
-#pragma unroll
-            for (int u = 0; u < U; u++) { const int k = c0 + u * DMPP_WAVE + lane; if (k < chunks) dst4[k] = a[u]; }
-        }
+        // LDS-DMA (global_load_lds_dwordx4): 1 KiB per wave instruction straight into LDS (destination = uniform base +
+        // lane * 16), no VGPR staging, so every piece of the 2 * N / 8 bytes is in flight at once
+        const int full = chunks & ~(DMPP_WAVE - 1);
+        for (int c0 = 0; c0 < full; c0 += DMPP_WAVE)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src4 + c0 + lane),
+                                             (__attribute__((address_space(3))) void*)(dst4 + c0), 16, 0, 0);
+        if (full + lane < chunks) dst4[full + lane] = src4[full + lane];
+        __builtin_amdgcn_s_waitcnt(0);
     }
     wave_sync();
 #ifdef DMPP_DEBUG_SEARCH
@@ -303,6 +304,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     const int gx = goal % W, gy = goal / W;
     const int cap = min(c.bucket_cap, kOpenCap);
     int status = -1, n_exp = 0, n_push = 0, n_rounds = 0, path_cost = 0;
+    bool hash_complete = true;                 // every closed cell is in the LDS hash (with its direction and run)
     uint64_t digest = 0;
 #ifdef DMPP_DEBUG_SEARCH
     long long t0 = clock64(), t_pop = 0, t_closed = 0, t_cand = 0, t_jump = 0, t_push = 0, t_done = 0; int c_iter = 0, c_jobs = 0, c_pass = 0, c_scan = 0, c_nt = 0;
@@ -321,38 +323,29 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
 #ifdef DMPP_DEBUG_SEARCH
         t_tr = clock64();
 #endif
-        // word summaries of both views (bit = word != 0): 64 consecutive words per ballot when a line is a
-        // power-of-two number of words, else word by word
+        // word summaries of both views (bit w of a line's summary = word w of the line is non-zero): one lane per line,
+        // 16-byte reads when a line is a whole number of them
         for (int v = 0; v < 2; v++) {
             const uint32_t* src = v ? bmT : bm;
             uint32_t* nz = v ? nz_col : nz_row;
-            const int LW = v ? HW : WW, NL = v ? W : H, SW = v ? SWc : SWr, total = NL * LW;
-            if ((LW & (LW - 1)) == 0 && LW <= 64) {
-                const int lw_log = 31 - __clz(LW);
-                const int piece = min(LW, 32), npiece = DMPP_WAVE / piece;
-                const unsigned long long pmask = piece == 32 ? 0xFFFFFFFFull : ((1ull << piece) - 1ull);
-                const int psh = (lane < npiece ? lane : 0) * piece;
-                constexpr int UN = 8;
-                for (int c0 = 0; c0 < total; c0 += DMPP_WAVE * UN) {
-                    uint32_t wv[UN];
-#pragma unroll
-                    for (int u = 0; u < UN; u++) wv[u] = src[min(c0 + u * DMPP_WAVE + lane, total - 1)];
-#pragma unroll
-                    for (int u = 0; u < UN; u++) {
-                        const int cu = c0 + u * DMPP_WAVE;
-                        const unsigned long long b = __ballot(wv[u] != 0u && cu + lane < total);
-                        const int w = cu + lane * piece;
-                        if (lane < npiece && w < total) nz[(w >> lw_log) * SW + ((w & (LW - 1)) >> 5)] = (uint32_t)((b >> psh) & pmask);
+            const int LW = v ? HW : WW, NL = v ? W : H, SW = v ? SWc : SWr;
+            for (int line = lane; line < NL; line += DMPP_WAVE) {
+                uint32_t lo = 0, hi = 0;
+                if ((LW & 3) == 0) {
+                    const uint4* p4 = reinterpret_cast<const uint4*>(src + line * LW);
+                    for (int q = 0; q < (LW >> 2); q++) {
+                        const uint4 a = p4[q];
+                        const uint32_t nib = min(a.x, 1u) | (min(a.y, 1u) << 1) | (min(a.z, 1u) << 2) | (min(a.w, 1u) << 3);
+                        if (q < 8) lo |= nib << (4 * q); else hi |= nib << (4 * (q - 8));
+                    }
+                } else {
+                    for (int w = 0; w < LW; w++) {
+                        const uint32_t bit = min(src[line * LW + w], 1u);
+                        if (w < 32) lo |= bit << w; else hi |= bit << (w - 32);
                     }
                 }
-            } else {
-                for (int i = lane; i < NL * SW; i += DMPP_WAVE) {
-                    const uint32_t* p = src + (i / SW) * LW + ((i % SW) << 5);
-                    const int nw = min(32, LW - ((i % SW) << 5));
-                    uint32_t m = 0;
-                    for (int b = 0; b < nw; b++) m |= (p[b] != 0u ? 1u : 0u) << b;
-                    nz[i] = m;
-                }
+                nz[line * SW] = lo;
+                if (SW > 1) nz[line * SW + 1] = hi;
             }
         }
 #ifdef DMPP_DEBUG_SEARCH
@@ -456,14 +449,17 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
                     uint32_t hh = ((uint32_t)cell * 2654435761u) >> (32 - kClosedLog);
                     for (int probe = 0; probe < kClosedTab; probe++) {
                         const uint32_t old = atomicCAS(&c_tab[hh], 0u, keyc);
-                        if (old == 0u) break;                                 // inserted: was open
+                        if (old == 0u) { c_info[hh] = (uint16_t)(d | (run_in << 4)); break; }   // inserted: was open
                         if (old == keyc) { valid = false; break; }            // already closed
                         hh = (hh + 1) & (kClosedTab - 1);
                     }
                 }
-            } else if (valid) {
-                const uint32_t old = atomicOr(&closed[cell >> 5], 1u << (cell & 31));
-                if ((old >> (cell & 31)) & 1u) valid = false;
+            } else {
+                hash_complete = false;
+                if (valid) {
+                    const uint32_t old = atomicOr(&closed[cell >> 5], 1u << (cell & 31));
+                    if ((old >> (cell & 31)) & 1u) valid = false;
+                }
             }
             // the goal, or the entry that reaches the expansion limit, ends the search at once
             unsigned vm = (unsigned)__ballot(valid) & 0xFu;
@@ -622,7 +618,64 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
         digest += ((uint64_t)hi << 32) | lo;
     }
     int path_len = 0;
-    if (status == DMPP_G_FOUND) {
+    bool slow_walk = !hash_complete;           // the HBM copy of direction | run answers instead of the LDS hash
+    if (status == DMPP_G_FOUND && hash_complete) {
+        // Walk the runs back from the goal: lane 0 looks each closed cell up in the LDS hash (direction and run sit in
+        // the same slot) and lists the hops in the LDS arrays of the dead open list.  The length is then known before
+        // a cell is written, so every cell goes straight to its final place, path[keep-1-k] for the k-th cell counted
+        // from the goal: one lane per hop, offsets from a wave prefix sum of the run lengths.
+        int L = 1, hops = 0, bad = 0;          // bad: 1 = inconsistent closed set, 2 = more hops than the LDS list holds
+        if (lane == 0) {
+            int cur = goal;
+            while (cur != start) {
+                if (hops >= kOpenCap) { bad = 2; break; }
+                uint32_t hh = ((uint32_t)cur * 2654435761u) >> (32 - kClosedLog);
+                int v = -1;
+                for (int probe = 0; probe < kClosedTab; probe++) {
+                    const uint32_t e2 = c_tab[hh]; const int inf = c_info[hh];
+                    if (e2 == (uint32_t)cur + 1u) { v = inf; break; }
+                    if (e2 == 0u) break;
+                    hh = (hh + 1) & (kClosedTab - 1);
+                }
+                const int pd = v & 15, rn = v >> 4;
+                if (v < 0 || rn == 0 || pd > 7) { bad = 1; break; }
+                // dx, dy of direction pd from two packed tables (2 bits each, value + 1)
+                const int dx = (int)((0x901Au >> (2 * pd)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * pd)) & 3u) - 1;
+                const int step = dy * W + dx;
+                o_ent[hops] = (uint32_t)cur; o_run[hops] = (uint16_t)rn; o_f2[hops] = (uint16_t)pd;
+                hops++; L += rn; cur -= rn * step;
+            }
+        }
+        L = __builtin_amdgcn_readfirstlane(L);
+        hops = __builtin_amdgcn_readfirstlane(hops);
+        bad = __builtin_amdgcn_readfirstlane(bad);
+        wave_sync();
+        if (bad == 1) status = DMPP_G_INTERNAL;
+        else if (bad == 2) slow_walk = true;
+        else {
+            int keep = L;
+            if (L > c.max_path) { keep = c.max_path; status = DMPP_G_PATH_TRUNC; }
+            path_len = keep;
+            int kbase = 0;
+            for (int j0 = 0; j0 < hops; j0 += DMPP_WAVE) {
+                const int j = j0 + lane;
+                const int rn = j < hops ? (int)o_run[j] : 0;
+                int incl = rn;
+#pragma unroll
+                for (int sft = 1; sft < DMPP_WAVE; sft <<= 1) { const int t = __shfl_up(incl, sft, 64); if (lane >= sft) incl += t; }
+                if (rn) {
+                    const int ec = (int)o_ent[j], pd = o_f2[j];
+                    const int dx = (int)((0x901Au >> (2 * pd)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * pd)) & 3u) - 1;
+                    const int step = dy * W + dx;
+                    int idx = kbase + incl - rn;
+                    for (int r = 0; r < rn && idx < keep; r++, idx++) path[keep - 1 - idx] = ec - r * step;
+                }
+                kbase += __shfl(incl, DMPP_WAVE - 1, 64);
+            }
+            if (lane == 0 && keep == L) path[0] = start;
+        }
+    }
+    if (status == DMPP_G_FOUND && slow_walk) {
         // Walk the runs back from the goal (lane 0 follows dir/run of each closed cell; it wrote them
         // itself), a chunk of runs at a time through the LDS arrays of the dead open list; all lanes
         // write the cells of a chunk goal-first into path[], which is reversed in place at the end.

@@ -164,7 +164,7 @@ typedef struct SceneIn {
 
 #define DMPP_JPS_BATCH 4       /* entries of the minimal f taken per step of the jump-point search */
 #define DMPP_DIAG_JUMP 8       /* cells a diagonal jump of the jump-point search looks ahead before it settles for a plain node */
-#define DMPP_OPEN_CAP 960      /* live entries of the jump-point search's open list (LDS resident: 4 scenes per CU) */
+#define DMPP_OPEN_CAP 512      /* live entries of the jump-point search's open list (LDS resident; 496 is the most any generated scene needs) */
 
 #define DMPP_MAX_LATTICE 17   /* n_lattice Bezier candidates + 1 grid-path candidate */
 

@@ -44,7 +44,7 @@ struct pp_planner {
     GlobalPoint2D* d_dec_ref = nullptr;
     // grid engine
     uint8_t* d_grid = nullptr; uint16_t* d_pinfo = nullptr; uint32_t* d_closed = nullptr;
-    int32_t* d_order = nullptr; int32_t* d_path = nullptr; uint32_t* d_gbm = nullptr;
+    int32_t* d_order = nullptr; int32_t* d_path = nullptr; uint32_t* d_gbm = nullptr; int32_t* d_perm = nullptr;
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
     bool search_gbm = false; int search_lds = 0; int raster_band_rows = 0;
@@ -144,6 +144,7 @@ int setup_grid_launch(pp_planner* h)
             h->search_gbm = true; h->search_lds = (int)nz_bytes;
         }
     }
+    if (!h->d_perm) { int r = dmalloc(&h->d_perm, (size_t)h->caps.max_scenes); if (r) return r; }
     if (!h->d_gbm) {          // bit-packed occupancy, row- and column-major: written by k_rasterise, read by k_search
         int r = dmalloc(&h->d_gbm, (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
         if (r) return r;
@@ -211,7 +212,7 @@ int pp_destroy(pp_handle h)
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now, h->d_state, h->d_plan, h->d_gout,
-                     h->d_dec_ref, h->d_grid, h->d_pinfo, h->d_closed, h->d_order, h->d_path, h->d_gbm, h->d_scratch };
+                     h->d_dec_ref, h->d_grid, h->d_pinfo, h->d_closed, h->d_order, h->d_path, h->d_gbm, h->d_perm, h->d_scratch };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -313,12 +314,13 @@ int pp_plan_tick(pp_handle h)
         {
             Timed t(h, PP_K_SEARCH);
             (void)hipMemsetAsync(h->d_closed, 0, (size_t)n * ((size_t)c.grid_w * c.grid_h / 8), h->stream);   // the closed bit sets
+            hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, h->stream, n, h->d_gout, h->d_perm);
             if (h->search_gbm)
-                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap, h->d_in,
+                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap, h->d_perm, h->d_in,
                                    h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, h->d_gbm);
             else
                 hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap,
-                                   h->d_in, h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, h->d_gbm);
+                                   h->d_perm, h->d_in, h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, h->d_gbm);
         }
         {
             Timed t(h, PP_K_SCORE);

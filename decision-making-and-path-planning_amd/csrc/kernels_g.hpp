@@ -244,9 +244,28 @@ __device__ __forceinline__ int jump_lane(const View& V, bool active, int line, i
     return run;
 }
 
+// Launch order of the scenes of k_search: heaviest first, by the cells the scene expanded on the previous tick (its
+// cost changes little from tick to tick).  One wave per scene and two waves per CU means the kernel ends with its
+// slowest scene; starting that scene first keeps it off the tail.  Counting sort into 64 cost classes, one block.
+constexpr int kOrderBlock = 1024, kOrderClasses = 64;
+__global__ void __launch_bounds__(kOrderBlock)
+k_order(int n_scenes, const GridOut* __restrict__ gout, int32_t* __restrict__ perm)
+{
+    __shared__ int cnt[kOrderClasses], base[kOrderClasses];
+    const int tid = threadIdx.x;
+    if (tid < kOrderClasses) cnt[tid] = 0;
+    __syncthreads();
+    for (int s = tid; s < n_scenes; s += kOrderBlock) atomicAdd(&cnt[kOrderClasses - 1 - min(gout[s].n_expanded >> 3, kOrderClasses - 1)], 1);
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int k = 0; k < kOrderClasses; k++) { base[k] = acc; acc += cnt[k]; } }
+    __syncthreads();
+    for (int s = tid; s < n_scenes; s += kOrderBlock)
+        perm[atomicAdd(&base[kOrderClasses - 1 - min(gout[s].n_expanded >> 3, kOrderClasses - 1)], 1)] = s;
+}
+
 template <bool GBM>
 __global__ void __launch_bounds__(DMPP_WAVE)
-k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict__ in,
+k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
          uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
          int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps)
 {
@@ -258,8 +277,8 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const SceneIn* __restrict
     __shared__ uint32_t sj_job[kDiagGroup]; __shared__ int sj_run[kDiagGroup]; // its straight jumps (<= 8)
     __shared__ uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
     __shared__ uint16_t c_info[kClosedTab];    // arriving direction | run length << 4 of the cell in the same slot
-    const int scene = blockIdx.x;
-    if (scene >= n_scenes) return;
+    if ((int)blockIdx.x >= n_scenes) return;
+    const int scene = perm[blockIdx.x];        // heaviest scenes first (k_order)
 #ifdef DMPP_DEBUG_SEARCH
     const long long t_entry = clock64(); long long t_loop = t_entry;
 #endif

@@ -528,11 +528,12 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
 #ifdef DMPP_DEBUG_SEARCH
             long long td = clock64(); t_cand += td - tc;
 #endif
-            // ---- jumps.  Every straight scan is one lane (jump_lane).  The straight successors of the batch (<= 8; 4 for
-            //      the start node) and the diagonal ones share the wave: a diagonal jump takes kDiagGroup lanes =
-            //      (cell 1..kDiagK along the diagonal) x (its horizontal | vertical straight jump), and the first cell
-            //      that is blocked / the goal / forced / a jump-off point ends it.  Round 0 = three diagonal jumps on
-            //      lanes 0..47 + the straight ones on lanes 48..63; further rounds (rare) = four diagonal jumps each ----
+            // ---- jumps.  Every straight scan is one lane (jump_lane).  A diagonal jump takes a group of kDiagGroup = 16
+            //      lanes: lane pair k = 0..6 scans horizontally | vertically from cell k+1 of the diagonal and its even lane
+            //      tests that cell (blocked / goal / forced); cell 8 only needs the test (whatever a scan found there, the
+            //      jump ends at that cell), so the last pair of every group is free for the straight successors of the
+            //      batch (<= 8; 4 for the start node).  Four diagonal jumps + all straight ones per round; a second round
+            //      only when a step has more than four diagonal successors.  The first cell with a finding ends a jump. ----
             const unsigned smask = (unsigned)__ballot(want_jump), dmask = (unsigned)__ballot(want_diag);
             const int n_sj = __popc(smask), n_dc = __popc(dmask);
             const int my_sj = __popc(smask & ((1u << (lane & 31)) - 1u)), my_dc = __popc(dmask & ((1u << (lane & 31)) - 1u));
@@ -543,35 +544,36 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
             }
             if (want_diag) dc_owner[my_dc] = lane;
             wave_order();
-            const int n_rounds_j = (n_sj | n_dc) ? 1 + (max(n_dc - 3, 0) + kDiagPerRound - 1) / kDiagPerRound : 0;
+            const int n_rounds_j = (n_sj | n_dc) ? max(1, (n_dc + kDiagPerRound - 1) / kDiagPerRound) : 0;
             for (int rnd = 0; rnd < n_rounds_j; rnd++) {
                 const int grp = lane / kDiagGroup, t = lane % kDiagGroup, kk = t >> 1;
-                const bool is_s = rnd == 0 && grp == kDiagPerRound - 1;            // the straight-jump lanes of round 0
-                const int dci = rnd == 0 ? grp : (kDiagPerRound - 1) + (rnd - 1) * kDiagPerRound + grp;
-                const bool dact = !is_s && dci < n_dc, sact = is_s && t < n_sj;
+                const bool last = kk == kDiagK - 1;                                // the pair of cell 8 = the straight-jump lanes
+                const int dci = rnd * kDiagPerRound + grp;
+                const int sji = grp * 2 + (t & 1);
+                const bool dact = dci < n_dc, sact = rnd == 0 && last && sji < n_sj;
                 const int ol = dc_owner[dact ? dci : 0];
                 const int ox = __shfl(nx0, ol, 64), oy = __shfl(ny0, ol, 64);
                 const int os = ol & 7;
                 const int odx = (os == 1 || os == 7) ? 1 : -1, ody = (os == 1 || os == 3) ? 1 : -1;
                 const int cx = ox + (kk + 1) * odx, cy = oy + (kk + 1) * ody;
-                const uint32_t sj = sj_job[sact ? t : 0];
+                const uint32_t sj = sj_job[sact ? sji : 0];
                 bool hv = (t & 1) != 0;                                            // vertical scan?
                 int jl = hv ? cx : cy, jp = hv ? cy : cx, jsg = hv ? ody : odx;
-                if (is_s) { hv = (sj & 1u) != 0; jsg = (sj & 2u) ? 1 : -1; jl = (int)((sj >> 2) & 0xFFFu); jp = (int)(sj >> 14); }
+                if (last) { hv = (sj & 1u) != 0; jsg = (sj & 2u) ? 1 : -1; jl = (int)((sj >> 2) & 0xFFFu); jp = (int)(sj >> 14); }
                 const View V = hv ? Vcol : Vrow;
-                #ifdef DMPP_DEBUG_SEARCH
-                const int r = jump_lane(V, dact || sact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx, &c_scan);
+#ifdef DMPP_DEBUG_SEARCH
+                const int r = jump_lane(V, last ? sact : dact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx, &c_scan);
 #else
-                const int r = jump_lane(V, dact || sact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx);
+                const int r = jump_lane(V, last ? sact : dact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx);
 #endif
-                if (sact) sj_run[t] = r;
+                if (sact) sj_run[sji] = r;
                 bool cblk = false, cstop = false;
                 if (dact && (t & 1) == 0) {
                     cblk = B.blk(cx, cy);
                     const bool forced = (B.blk(cx - odx, cy) && !B.blk(cx - odx, cy + ody)) || (B.blk(cx, cy - ody) && !B.blk(cx + odx, cy - ody));
                     cstop = cblk || (cx == gx && cy == gy) || forced;
                 }
-                const unsigned long long sm = __ballot(dact && (cstop || r > 0)), bk = __ballot(cblk);
+                const unsigned long long sm = __ballot(dact && (cstop || (!last && r > 0))), bk = __ballot(cblk);
                 const unsigned gs = (unsigned)(sm >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
                 const unsigned gb = (unsigned)(bk >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
                 int drun = kDiagK;

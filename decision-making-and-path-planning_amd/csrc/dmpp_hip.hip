@@ -48,6 +48,7 @@ struct pp_planner {
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
     bool search_gbm = false; int search_lds = 0; int raster_band_rows = 0;
+    hipStream_t stream_r = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the R kernels run beside the grid engine
     // op scratch (stand-alone operators)
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
     // profiling
@@ -89,12 +90,12 @@ hipEvent_t get_event(pp_planner* h)
 }
 
 struct Timed {
-    pp_planner* h; int k; hipEvent_t a = nullptr, b = nullptr;
-    Timed(pp_planner* h_, int k_) : h(h_), k(k_) {
-        if (h->profile) { a = get_event(h); b = get_event(h); if (a) (void)hipEventRecord(a, h->stream); }
+    pp_planner* h; int k; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    Timed(pp_planner* h_, int k_, hipStream_t st_ = nullptr) : h(h_), k(k_), st(st_ ? st_ : h_->stream) {
+        if (h->profile) { a = get_event(h); b = get_event(h); if (a) (void)hipEventRecord(a, st); }
     }
     ~Timed() {
-        if (h->profile && a && b) { (void)hipEventRecord(b, h->stream); h->pending.push_back({a, b, k}); }
+        if (h->profile && a && b) { (void)hipEventRecord(b, st); h->pending.push_back({a, b, k}); }
     }
 };
 
@@ -174,6 +175,9 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     h->cfg = *cfg; h->caps = *caps; h->device = device;
     auto bail = [&](int code) { pp_destroy(h); return code; };
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithFlags(&h->stream_r, hipStreamNonBlocking) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
     const size_t ns = (size_t)caps->max_scenes;
     if ((r = dmalloc(&h->d_in, ns))) return bail(r);
     if ((r = dmalloc(&h->d_lane, (size_t)caps->max_lane_pts_total))) return bail(r);
@@ -214,6 +218,9 @@ int pp_destroy(pp_handle h)
     void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now, h->d_state, h->d_plan, h->d_gout,
                      h->d_dec_ref, h->d_grid, h->d_pinfo, h->d_closed, h->d_order, h->d_path, h->d_gbm, h->d_perm, h->d_scratch };
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->stream_r) { (void)hipStreamSynchronize(h->stream_r); (void)hipStreamDestroy(h->stream_r); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PP_OK;
@@ -293,16 +300,24 @@ int pp_plan_tick(pp_handle h)
         hipLaunchKernelGGL(dmpp::k_effective_obstacles, dim3(n), dim3(dmpp::kBlock), 0, h->stream, c, n, h->d_in, h->d_state,
                            h->d_obs, h->have_motion ? h->d_mot : nullptr, h->d_obs_now);
     }
+    // The Decision + Planning kernels (Part R) and the grid engine (Part G) share nothing but the obstacle snapshot:
+    // with the grid stage on, Part R runs on a second stream beside it (the search leaves most CUs idle in its tail).
+    hipStream_t sr = c.grid_stage ? h->stream_r : h->stream;
+    if (c.grid_stage) {
+        HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+        HIP_TRY(hipStreamWaitEvent(sr, h->ev_fork, 0));
+    }
     if (c.decision_stage) {
-        Timed t(h, PP_K_DECISION);
-        hipLaunchKernelGGL(dmpp::k_decision, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::DecShared), h->stream, c, n, h->d_in, h->d_lane,
+        Timed t(h, PP_K_DECISION, sr);
+        hipLaunchKernelGGL(dmpp::k_decision, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::DecShared), sr, c, n, h->d_in, h->d_lane,
                            h->d_attr, h->d_ref, h->d_obs_now, h->d_state, h->d_plan, h->d_dec_ref);
     }
     {
-        Timed t(h, PP_K_PLANNING);
-        hipLaunchKernelGGL(dmpp::k_planning, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::PlanShared), h->stream, c, n, h->d_in, h->d_lane,
+        Timed t(h, PP_K_PLANNING, sr);
+        hipLaunchKernelGGL(dmpp::k_planning, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::PlanShared), sr, c, n, h->d_in, h->d_lane,
                            h->d_ref, h->d_dec_ref, h->d_obs_now, h->d_state, h->d_plan);
     }
+    if (c.grid_stage) HIP_TRY(hipEventRecord(h->ev_join, sr));
     if (c.grid_stage) {
         {
             Timed t(h, PP_K_RASTERISE);
@@ -327,6 +342,7 @@ int pp_plan_tick(pp_handle h)
             hipLaunchKernelGGL(dmpp::k_score, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::ScoreShared), h->stream, c, n, h->d_in, h->d_obs_now,
                                h->d_path, h->d_gout);
         }
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));        // the tick is complete on the handle's stream
     }
     HIP_TRY(hipGetLastError());
     return PP_OK;

@@ -194,7 +194,7 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     if (cfg->grid_stage) {
         h->grid_cells = (size_t)cfg->grid_w * cfg->grid_h;
         h->bucket_cap0 = cfg->bucket_cap; h->max_path0 = cfg->max_path;
-        if ((r = dmalloc(&h->d_grid, ns * h->grid_cells))) return bail(r);
+        if ((r = dmalloc(&h->d_grid, h->grid_cells))) return bail(r);             // one scene as bytes, filled on demand (pp_get_grid)
         if ((r = dmalloc(&h->d_pinfo, ns * h->grid_cells))) return bail(r);
         if ((r = dmalloc(&h->d_closed, ns * (h->grid_cells / 32)))) return bail(r);
         if ((r = dmalloc(&h->d_path, ns * (size_t)cfg->max_path))) return bail(r);
@@ -324,7 +324,7 @@ int pp_plan_tick(pp_handle h)
             const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
             const size_t lds = 2 * ((size_t)h->raster_band_rows * c.grid_w / 8);      // the band row-major and column-major
             hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, h->stream, c, n, h->raster_band_rows,
-                               h->d_in, h->d_obs_now, h->d_grid, h->d_gbm);
+                               h->d_in, h->d_obs_now, h->d_gbm);
         }
         {
             Timed t(h, PP_K_SEARCH);
@@ -387,7 +387,12 @@ int pp_get_grid(pp_handle h, int scene, uint8_t* grid)
     if (!h || !grid || !h->d_grid) return fail(PP_ERR_ARG, "no grid");
     if (scene < 0 || scene >= h->n_scenes) return fail(PP_ERR_ARG, "scene out of range");
     const size_t N = (size_t)h->cfg.grid_w * h->cfg.grid_h;
-    return fetch(h, grid, h->d_grid + (size_t)scene * N, N);
+    // the tick keeps the grid bit-packed; its byte form is produced here, for the one scene asked for
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(dmpp::k_expand_grid, dim3((unsigned)((N / 16 + dmpp::kRasterBlock - 1) / dmpp::kRasterBlock)), dim3(dmpp::kRasterBlock), 0,
+                       h->stream, h->cfg.grid_w, h->cfg.grid_h, h->d_gbm + (size_t)scene * 2 * (N / 32), h->d_grid);
+    HIP_TRY(hipGetLastError());
+    return fetch(h, grid, h->d_grid, N);
 }
 int pp_get_order(pp_handle h, int scene, int32_t* order, int cap)
 {
@@ -668,7 +673,7 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes)
     case PP_BUF_STATE: p = h->d_state; b = ns * sizeof(SceneState); break;
     case PP_BUF_PLAN_OUT: p = h->d_plan; b = ns * sizeof(PlanOut); break;
     case PP_BUF_GRID_OUT: p = h->d_gout; b = ns * sizeof(GridOut); break;
-    case PP_BUF_GRID: p = h->d_grid; b = ns * h->grid_cells; break;
+    case PP_BUF_GRID: p = h->d_gbm; b = ns * 2 * (h->grid_cells / 8); break;      // bit-packed: per scene row-major then column-major
     case PP_BUF_PATH: p = h->d_path; b = ns * (size_t)h->max_path0 * 4; break;
     case PP_BUF_LANE_ATTR: p = h->d_attr; b = (size_t)h->caps.max_lane_pts_total; break;
     case PP_BUF_ORDER: p = h->d_order; b = ns * (size_t)h->caps.order_cap * 4; break;

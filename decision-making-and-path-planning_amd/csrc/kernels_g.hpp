@@ -39,7 +39,7 @@ constexpr int kRasterBlock = 256;
 
 __global__ void __launch_bounds__(kRasterBlock)
 k_rasterise(PlannerConfig c, int n_scenes, int band_rows, const SceneIn* __restrict__ in,
-            const ObPoint* __restrict__ obs_now, uint8_t* __restrict__ grid, uint32_t* __restrict__ gbits)
+            const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gbits)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int scene = blockIdx.x, band = blockIdx.y;
@@ -102,24 +102,29 @@ k_rasterise(PlannerConfig c, int n_scenes, int band_rows, const SceneIn* __restr
         __syncthreads();
     }
     __syncthreads();
-    // (1) the occupancy grid proper: expand 16 bits -> 16 bytes per lane per store (uint4), fully coalesced
-    uint4* out = reinterpret_cast<uint4*>(grid + ((size_t)scene * H + row0) * W);
-    const int chunks = (rows * W) >> 4;
-    for (int k = tid; k < chunks; k += kRasterBlock) {
-        const uint32_t w = bits[k >> 1];
+    // the occupancy grid, bit-packed: row-major (H x WW words) then column-major (W x HW words)
+    uint32_t* brow = gbits + (size_t)scene * 2 * ((size_t)(W * H) >> 5);
+    uint32_t* bcol = brow + ((size_t)(W * H) >> 5);
+    for (int w = tid; w < words; w += kRasterBlock) brow[row0 * WW + w] = bits[w];
+    for (int w = tid; w < words; w += kRasterBlock) bcol[(w / bw) * HW + (row0 >> 5) + (w % bw)] = bitsT[w];
+}
+
+// The occupancy grid of one scene as bytes (0 free / 1 occupied), for pp_get_grid: 16 bits -> 16 bytes per thread.
+__global__ void __launch_bounds__(kRasterBlock)
+k_expand_grid(int grid_w, int grid_h, const uint32_t* __restrict__ brow, uint8_t* __restrict__ out)
+{
+    const int chunks = (grid_w * grid_h) >> 4;
+    uint4* o4 = reinterpret_cast<uint4*>(out);
+    for (int k = blockIdx.x * kRasterBlock + threadIdx.x; k < chunks; k += gridDim.x * kRasterBlock) {
+        const uint32_t w = brow[k >> 1];
         const uint32_t h16 = (k & 1) ? (w >> 16) : (w & 0xFFFFu);
         uint4 v;
         v.x = ((h16 & 0xFu) * 0x00204081u) & 0x01010101u;
         v.y = (((h16 >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
         v.z = (((h16 >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
         v.w = (((h16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u;
-        out[k] = v;
+        o4[k] = v;
     }
-    // (2) its bit-packed forms for the search: row-major (H x WW words) then column-major (W x HW words)
-    uint32_t* brow = gbits + (size_t)scene * 2 * ((size_t)(W * H) >> 5);
-    uint32_t* bcol = brow + ((size_t)(W * H) >> 5);
-    for (int w = tid; w < words; w += kRasterBlock) brow[row0 * WW + w] = bits[w];
-    for (int w = tid; w < words; w += kRasterBlock) bcol[(w / bw) * HW + (row0 >> 5) + (w % bw)] = bitsT[w];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -324,6 +329,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     const int cap = min(c.bucket_cap, kOpenCap);
     int status = -1, n_exp = 0, n_push = 0, n_rounds = 0, path_cost = 0;
     bool hash_complete = true;                 // every closed cell is in the LDS hash (with its direction and run)
+    uint32_t start_was_set = 0;                // lane 0: the start cell was occupied in the grid (restored in HBM at the end)
     uint64_t digest = 0;
 #ifdef DMPP_DEBUG_SEARCH
     long long t0 = clock64(), t_pop = 0, t_closed = 0, t_cand = 0, t_jump = 0, t_push = 0, t_done = 0; int c_iter = 0, c_jobs = 0, c_pass = 0, c_scan = 0, c_nt = 0;
@@ -334,6 +340,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     } else {
         if (lane == 0) {                                                    // the vehicle is where it is
             const int sx = start % W, sy = start / W;
+            start_was_set = (bm[start >> 5] >> (start & 31)) & 1u;
             bm[start >> 5] &= ~(1u << (start & 31));
             bmT[sx * HW + (sy >> 5)] &= ~(1u << (sy & 31));
         }
@@ -752,6 +759,11 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     if (lane == 0) { long long te = clock64(); int32_t* dbg = path + c.max_path - 16; dbg[0] = c_iter; dbg[1] = c_scan; dbg[2] = c_jobs; dbg[3] = c_pass; dbg[4] = c_scan;
         dbg[5] = (int)(t_pop >> 4); dbg[6] = (int)(t_closed >> 4); dbg[7] = (int)(t_cand >> 4); dbg[8] = (int)(t_jump >> 4); dbg[9] = (int)(t_push >> 4); dbg[10] = (int)((te - t_done) >> 4); dbg[11] = (int)((te - t0) >> 4); dbg[12] = (int)((t_loop - t_entry) >> 4); dbg[13] = (int)((te - t_entry) >> 4); dbg[14] = (int)((t_pack - t_entry) >> 4); dbg[15] = (int)((t_tr - t_pack) >> 4); dbg[4] = (int)((t_nz - t_tr) >> 4); }
 #endif
+    if (GBM && lane == 0 && start_was_set) {           // the bitmaps in HBM are the grid pp_get_grid returns: leave them as rasterised
+        const int sx = start % W, sy = start / W;
+        bm[start >> 5] |= 1u << (start & 31);
+        bmT[sx * HW + (sy >> 5)] |= 1u << (sy & 31);
+    }
     if (lane == 0) {
         go.order_digest = digest; go.status = status; go.n_expanded = n_exp; go.n_pushed = n_push; go.n_rounds = n_rounds;
         go.path_len = path_len; go.path_cost = path_cost; go.start_cell = start; go.goal_cell = goal;

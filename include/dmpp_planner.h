@@ -88,7 +88,7 @@ int  pp_sync(pp_handle h);
 int  pp_get_plan(pp_handle h, PlanOut* out, int n_scenes);
 int  pp_get_state(pp_handle h, SceneState* state, int n_scenes);
 int  pp_get_grid_out(pp_handle h, GridOut* out, int n_scenes);
-int  pp_get_grid(pp_handle h, int scene, uint8_t* grid);                 /* grid_w*grid_h bytes */
+int  pp_get_grid(pp_handle h, int scene, uint8_t* grid);                 /* grid_w*grid_h bytes (expanded on demand: the tick keeps the grid bit-packed) */
 int  pp_get_order(pp_handle h, int scene, int32_t* order, int cap);      /* needs caps.order_cap > 0 */
 int  pp_get_path(pp_handle h, int scene, int32_t* path, int cap);
 /* DecisionOut.refpath published by the decision stage (Decision.cpp:195); PlanOut.dec.refpath_n points are valid */

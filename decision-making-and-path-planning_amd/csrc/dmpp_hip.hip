@@ -37,18 +37,24 @@ struct pp_planner {
     hipStream_t stream = nullptr;
     // inputs
     SceneIn* d_in = nullptr; GlobalPoint3D* d_lane = nullptr; uint8_t* d_attr = nullptr; bool have_attr = false; GlobalPoint2D* d_ref = nullptr;
-    ObPoint* d_obs = nullptr; ObMotion* d_mot = nullptr; ObPoint* d_obs_now = nullptr;
+    ObPoint* d_obs = nullptr; ObMotion* d_mot = nullptr; ObPoint* d_obs_now[2] = { nullptr, nullptr };
     bool have_motion = false;
     // state / outputs
-    SceneState* d_state = nullptr; PlanOut* d_plan = nullptr; GridOut* d_gout = nullptr;
+    SceneState* d_state = nullptr; PlanOut* d_plan = nullptr; GridOut* d_gout[2] = { nullptr, nullptr };
     GlobalPoint2D* d_dec_ref = nullptr;
     // grid engine
     uint8_t* d_grid = nullptr; uint16_t* d_pinfo = nullptr; uint32_t* d_closed = nullptr;
-    int32_t* d_order = nullptr; int32_t* d_path = nullptr; uint32_t* d_gbm = nullptr; int32_t* d_perm = nullptr;
+    int32_t* d_order = nullptr; int32_t* d_path[2] = { nullptr, nullptr }; uint32_t* d_gbm[2] = { nullptr, nullptr }; int32_t* d_perm = nullptr;
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
     bool search_gbm = false; int search_lds = 0; int raster_band_rows = 0;
     hipStream_t stream_r = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the R kernels run beside the grid engine
+    // k_score of tick t runs on its own stream beside the rasterise / search of tick t+1: the obstacle snapshot, the path
+    // cells and GridOut are double-buffered by tick parity; ev_score[p] = the last k_score that used the buffers p
+    hipStream_t stream_s = nullptr; hipEvent_t ev_search[2] = { nullptr, nullptr }, ev_score[2] = { nullptr, nullptr };
+    hipEvent_t ev_raster = nullptr;
+    bool score_recorded[2] = { false, false }, search_recorded[2] = { false, false }, front_recorded = false, front_unjoined = false;
+    int parity = 0;              // buffers of the last tick
     // op scratch (stand-alone operators)
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
     // profiling
@@ -89,6 +95,16 @@ hipEvent_t get_event(pp_planner* h)
     return e;
 }
 
+constexpr int kPipelineMinScenes = 256;      // batches at least this large run k_score beside the next tick's search
+
+// Everything a tick started is ordered before whatever the handle's stream does next.
+int join_score(pp_planner* h)
+{
+    for (int q = 0; q < 2; q++) if (h->score_recorded[q]) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_score[q], 0));
+    if (h->front_recorded) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    return PP_OK;
+}
+
 struct Timed {
     pp_planner* h; int k; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     Timed(pp_planner* h_, int k_, hipStream_t st_ = nullptr) : h(h_), k(k_), st(st_ ? st_ : h_->stream) {
@@ -102,6 +118,7 @@ struct Timed {
 int drain_events(pp_planner* h)
 {
     if (h->pending.empty()) return PP_OK;
+    { int r = join_score(h); if (r) return r; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (auto& p : h->pending) {
         float ms = 0;
@@ -146,8 +163,8 @@ int setup_grid_launch(pp_planner* h)
         }
     }
     if (!h->d_perm) { int r = dmalloc(&h->d_perm, (size_t)h->caps.max_scenes); if (r) return r; }
-    if (!h->d_gbm) {          // bit-packed occupancy, row- and column-major: written by k_rasterise, read by k_search
-        int r = dmalloc(&h->d_gbm, (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
+    for (int q = 0; q < 2; q++) if (!h->d_gbm[q]) {   // bit-packed occupancy, row- and column-major: written by k_rasterise, read by k_search
+        int r = dmalloc(&h->d_gbm[q], (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
         if (r) return r;
     }
     return PP_OK;
@@ -174,10 +191,20 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     if (!h) return fail(PP_ERR_HIP, "out of host memory");
     h->cfg = *cfg; h->caps = *caps; h->device = device;
     auto bail = [&](int code) { pp_destroy(h); return code; };
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
-    if (hipStreamCreateWithFlags(&h->stream_r, hipStreamNonBlocking) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    // the search chain gets the highest dispatch priority, the chains that run beside it the lowest: a waiting search
+    // workgroup (80 KB of LDS) must not queue behind the short kernels that fill the gaps
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithPriority(&h->stream_r, hipStreamNonBlocking, prio_least) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithPriority(&h->stream_s, hipStreamNonBlocking, prio_least) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_search[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_search[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_raster, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_score[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_score[1], hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
     const size_t ns = (size_t)caps->max_scenes;
     if ((r = dmalloc(&h->d_in, ns))) return bail(r);
     if ((r = dmalloc(&h->d_lane, (size_t)caps->max_lane_pts_total))) return bail(r);
@@ -185,19 +212,20 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     if ((r = dmalloc(&h->d_ref, (size_t)caps->max_ref_pts_total))) return bail(r);
     if ((r = dmalloc(&h->d_obs, (size_t)caps->max_obs_total))) return bail(r);
     if ((r = dmalloc(&h->d_mot, (size_t)caps->max_obs_total))) return bail(r);
-    if ((r = dmalloc(&h->d_obs_now, (size_t)caps->max_obs_total))) return bail(r);
+    for (int q = 0; q < 2; q++) if ((r = dmalloc(&h->d_obs_now[q], (size_t)caps->max_obs_total))) return bail(r);
     if ((r = dmalloc(&h->d_state, ns))) return bail(r);
     if ((r = dmalloc(&h->d_plan, ns))) return bail(r);
-    if ((r = dmalloc(&h->d_gout, ns))) return bail(r);
+    for (int q = 0; q < 2; q++) if ((r = dmalloc(&h->d_gout[q], ns))) return bail(r);
     if ((r = dmalloc(&h->d_dec_ref, ns * DMPP_MAX_REFPATH))) return bail(r);
-    if (hipMemsetAsync(h->d_gout, 0, ns * sizeof(GridOut), h->stream) != hipSuccess) return bail(fail(PP_ERR_HIP, "memset failed"));
+    for (int q = 0; q < 2; q++)
+        if (hipMemsetAsync(h->d_gout[q], 0, ns * sizeof(GridOut), h->stream) != hipSuccess) return bail(fail(PP_ERR_HIP, "memset failed"));
     if (cfg->grid_stage) {
         h->grid_cells = (size_t)cfg->grid_w * cfg->grid_h;
         h->bucket_cap0 = cfg->bucket_cap; h->max_path0 = cfg->max_path;
         if ((r = dmalloc(&h->d_grid, h->grid_cells))) return bail(r);             // one scene as bytes, filled on demand (pp_get_grid)
         if ((r = dmalloc(&h->d_pinfo, ns * h->grid_cells))) return bail(r);
         if ((r = dmalloc(&h->d_closed, ns * (h->grid_cells / 32)))) return bail(r);
-        if ((r = dmalloc(&h->d_path, ns * (size_t)cfg->max_path))) return bail(r);
+        for (int q = 0; q < 2; q++) if ((r = dmalloc(&h->d_path[q], ns * (size_t)cfg->max_path))) return bail(r);
         if (caps->order_cap > 0 && (r = dmalloc(&h->d_order, ns * (size_t)caps->order_cap))) return bail(r);
         if ((r = setup_grid_launch(h))) return bail(r);
     }
@@ -215,9 +243,14 @@ int pp_destroy(pp_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
-    void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now, h->d_state, h->d_plan, h->d_gout,
-                     h->d_dec_ref, h->d_grid, h->d_pinfo, h->d_closed, h->d_order, h->d_path, h->d_gbm, h->d_perm, h->d_scratch };
+    if (h->stream_s) (void)hipStreamSynchronize(h->stream_s);
+    void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now[0], h->d_obs_now[1], h->d_state, h->d_plan,
+                     h->d_gout[0], h->d_gout[1], h->d_dec_ref, h->d_grid, h->d_pinfo, h->d_closed, h->d_order, h->d_path[0], h->d_path[1],
+                     h->d_gbm[0], h->d_gbm[1], h->d_perm, h->d_scratch };
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (int q = 0; q < 2; q++) { if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]); if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]); }
+    if (h->ev_raster) (void)hipEventDestroy(h->ev_raster);
+    if (h->stream_s) (void)hipStreamDestroy(h->stream_s);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream_r) { (void)hipStreamSynchronize(h->stream_r); (void)hipStreamDestroy(h->stream_r); }
@@ -249,6 +282,7 @@ int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoin
         return fail(PP_ERR_CAPACITY, "pool larger than the capacity given to pp_create");
     if (n_lane_pts < 0 || n_ref_pts < 0 || n_obs_total < 0) return fail(PP_ERR_ARG, "negative size");
     HIP_TRY(hipSetDevice(h->device));
+    { int r = join_score(h); if (r) return r; }
     HIP_TRY(hipMemcpyAsync(h->d_in, in, (size_t)n_scenes * sizeof(SceneIn), hipMemcpyDefault, h->stream));
     if (n_lane_pts && lane_pool) HIP_TRY(hipMemcpyAsync(h->d_lane, lane_pool, (size_t)n_lane_pts * sizeof(GlobalPoint3D), hipMemcpyDefault, h->stream));
     h->have_attr = false;
@@ -281,6 +315,7 @@ int pp_set_state(pp_handle h, const SceneState* state, int n)
     if (!h || !state) return fail(PP_ERR_ARG, "null argument");
     if (n < 0 || n > h->caps.max_scenes) return fail(PP_ERR_CAPACITY, "n exceeds caps.max_scenes");
     HIP_TRY(hipSetDevice(h->device));
+    { int r = join_score(h); if (r) return r; }
     HIP_TRY(hipMemcpyAsync(h->d_state, state, (size_t)n * sizeof(SceneState), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PP_OK;
@@ -295,55 +330,75 @@ int pp_plan_tick(pp_handle h)
     const PlannerConfig& c = h->cfg;
     if (c.decision_stage && c.lanechg_stage && !h->have_attr)
         return fail(PP_ERR_ARG, "cfg.lanechg_stage needs the lane attribute pool (pp_set_scenes lane_attr_pool)");
+    // One tick = three chains.  FRONT (stream_r): obstacle snapshot, rasterise, Decision, Planning - short kernels;
+    // SEARCH (the handle's stream): k_order + k_search, the long one; SCORE (stream_s): k_score.  The obstacle snapshot,
+    // the bitmaps, the path cells and GridOut alternate between two buffers by tick parity, so the front of tick t+1
+    // and the score of tick t both run beside the search (which leaves most CUs idle in its tail):
+    //   front(t)  waits for score(t-2) [snapshot p] and search(t-2) [bitmaps p];
+    //   search(t) waits for rasterise(t) and score(t-2) [path / GridOut p];  score(t) waits for search(t).
+    // Small batches and ticks without the grid stage stay on one stream (a cross-stream hand-over costs tens of
+    // microseconds; only Decision + Planning run beside the grid engine there).
+    const int p = h->parity ^ 1;
+    const bool piped = c.grid_stage && n >= kPipelineMinScenes;
+    hipStream_t sm = h->stream;                                        // search chain
+    hipStream_t sf = piped ? h->stream_r : h->stream;                  // front chain
+    hipStream_t ss = piped ? h->stream_s : h->stream;                  // score chain
+    hipStream_t sr = c.grid_stage ? h->stream_r : h->stream;           // Decision + Planning
+    if (h->score_recorded[p]) { HIP_TRY(hipStreamWaitEvent(sf, h->ev_score[p], 0)); HIP_TRY(hipStreamWaitEvent(sm, h->ev_score[p], 0)); }
+    if (h->search_recorded[p]) HIP_TRY(hipStreamWaitEvent(sf, h->ev_search[p], 0));
+    if (h->front_recorded && sf == h->stream && h->front_unjoined) HIP_TRY(hipStreamWaitEvent(sf, h->ev_join, 0));   // Planning(t-1) -> snapshot(t) when not on the same stream
+    h->front_unjoined = false;
+    ObPoint* obs_now = h->d_obs_now[p];
     {
-        Timed t(h, PP_K_OBSTACLES);
-        hipLaunchKernelGGL(dmpp::k_effective_obstacles, dim3(n), dim3(dmpp::kBlock), 0, h->stream, c, n, h->d_in, h->d_state,
-                           h->d_obs, h->have_motion ? h->d_mot : nullptr, h->d_obs_now);
+        Timed t(h, PP_K_OBSTACLES, sf);
+        hipLaunchKernelGGL(dmpp::k_effective_obstacles, dim3(n), dim3(dmpp::kBlock), 0, sf, c, n, h->d_in, h->d_state,
+                           h->d_obs, h->have_motion ? h->d_mot : nullptr, obs_now);
     }
-    // The Decision + Planning kernels (Part R) and the grid engine (Part G) share nothing but the obstacle snapshot:
-    // with the grid stage on, Part R runs on a second stream beside it (the search leaves most CUs idle in its tail).
-    hipStream_t sr = c.grid_stage ? h->stream_r : h->stream;
+    if (sr != sf) { HIP_TRY(hipEventRecord(h->ev_fork, sf)); HIP_TRY(hipStreamWaitEvent(sr, h->ev_fork, 0)); }   // small batches: Decision + Planning beside the grid engine
     if (c.grid_stage) {
-        HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
-        HIP_TRY(hipStreamWaitEvent(sr, h->ev_fork, 0));
+        Timed t(h, PP_K_RASTERISE, sf);
+        const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
+        const size_t lds = 2 * ((size_t)h->raster_band_rows * c.grid_w / 8);      // the band row-major and column-major
+        hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, sf, c, n, h->raster_band_rows,
+                           h->d_in, obs_now, h->d_gbm[p]);
     }
+    if (sf != sm) HIP_TRY(hipEventRecord(h->ev_raster, sf));
     if (c.decision_stage) {
         Timed t(h, PP_K_DECISION, sr);
         hipLaunchKernelGGL(dmpp::k_decision, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::DecShared), sr, c, n, h->d_in, h->d_lane,
-                           h->d_attr, h->d_ref, h->d_obs_now, h->d_state, h->d_plan, h->d_dec_ref);
+                           h->d_attr, h->d_ref, obs_now, h->d_state, h->d_plan, h->d_dec_ref);
     }
     {
         Timed t(h, PP_K_PLANNING, sr);
         hipLaunchKernelGGL(dmpp::k_planning, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::PlanShared), sr, c, n, h->d_in, h->d_lane,
-                           h->d_ref, h->d_dec_ref, h->d_obs_now, h->d_state, h->d_plan);
+                           h->d_ref, h->d_dec_ref, obs_now, h->d_state, h->d_plan);
     }
-    if (c.grid_stage) HIP_TRY(hipEventRecord(h->ev_join, sr));
+    if (sr != h->stream) { HIP_TRY(hipEventRecord(h->ev_join, sr)); h->front_recorded = true; h->front_unjoined = piped; }
     if (c.grid_stage) {
+        if (sf != sm) HIP_TRY(hipStreamWaitEvent(sm, h->ev_raster, 0));
         {
-            Timed t(h, PP_K_RASTERISE);
-            const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
-            const size_t lds = 2 * ((size_t)h->raster_band_rows * c.grid_w / 8);      // the band row-major and column-major
-            hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, h->stream, c, n, h->raster_band_rows,
-                               h->d_in, h->d_obs_now, h->d_gbm);
-        }
-        {
-            Timed t(h, PP_K_SEARCH);
-            (void)hipMemsetAsync(h->d_closed, 0, (size_t)n * ((size_t)c.grid_w * c.grid_h / 8), h->stream);   // the closed bit sets
-            hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, h->stream, n, h->d_gout, h->d_perm);
+            Timed t(h, PP_K_SEARCH, sm);
+            (void)hipMemsetAsync(h->d_closed, 0, (size_t)n * ((size_t)c.grid_w * c.grid_h / 8), sm);   // the closed bit sets
+            hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_gout[p ^ 1], h->d_perm);   // by last tick's cost
             if (h->search_gbm)
-                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap, h->d_perm, h->d_in,
-                                   h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, h->d_gbm);
+                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap, h->d_perm, h->d_in,
+                                   h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p]);
             else
-                hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, h->stream, c, n, h->caps.order_cap,
-                                   h->d_perm, h->d_in, h->d_closed, h->d_pinfo, h->d_order, h->d_path, h->d_gout, h->d_gbm);
+                hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap,
+                                   h->d_perm, h->d_in, h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p]);
         }
+        h->search_recorded[p] = piped;                   // (one-stream mode: stream order is enough, no events on the latency path)
+        if (piped) { HIP_TRY(hipEventRecord(h->ev_search[p], sm)); HIP_TRY(hipStreamWaitEvent(ss, h->ev_search[p], 0)); }
         {
-            Timed t(h, PP_K_SCORE);
-            hipLaunchKernelGGL(dmpp::k_score, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::ScoreShared), h->stream, c, n, h->d_in, h->d_obs_now,
-                               h->d_path, h->d_gout);
+            Timed t(h, PP_K_SCORE, ss);
+            hipLaunchKernelGGL(dmpp::k_score, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::ScoreShared), ss, c, n, h->d_in, obs_now,
+                               h->d_path[p], h->d_gout[p]);
         }
-        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));        // the tick is complete on the handle's stream
+        h->score_recorded[p] = piped;
+        if (piped) HIP_TRY(hipEventRecord(h->ev_score[p], ss));
+        if (!piped && sr != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));   // one-stream mode: the tick is complete on the handle's stream
     }
+    h->parity = p;
     HIP_TRY(hipGetLastError());
     return PP_OK;
 }
@@ -352,6 +407,7 @@ int pp_sync(pp_handle h)
 {
     if (!h) return fail(PP_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    { int r = join_score(h); if (r) return r; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PP_OK;
 }
@@ -359,6 +415,7 @@ int pp_sync(pp_handle h)
 static int fetch(pp_handle h, void* dst, const void* src, size_t bytes)
 {
     HIP_TRY(hipSetDevice(h->device));
+    { int r = join_score(h); if (r) return r; }
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PP_OK;
@@ -380,7 +437,7 @@ int pp_get_grid_out(pp_handle h, GridOut* out, int n)
 {
     if (!h || !out) return fail(PP_ERR_ARG, "null argument");
     if (n < 0 || n > h->n_scenes) return fail(PP_ERR_ARG, "n exceeds the resident scenes");
-    return fetch(h, out, h->d_gout, (size_t)n * sizeof(GridOut));
+    return fetch(h, out, h->d_gout[h->parity], (size_t)n * sizeof(GridOut));
 }
 int pp_get_grid(pp_handle h, int scene, uint8_t* grid)
 {
@@ -390,7 +447,7 @@ int pp_get_grid(pp_handle h, int scene, uint8_t* grid)
     // the tick keeps the grid bit-packed; its byte form is produced here, for the one scene asked for
     HIP_TRY(hipSetDevice(h->device));
     hipLaunchKernelGGL(dmpp::k_expand_grid, dim3((unsigned)((N / 16 + dmpp::kRasterBlock - 1) / dmpp::kRasterBlock)), dim3(dmpp::kRasterBlock), 0,
-                       h->stream, h->cfg.grid_w, h->cfg.grid_h, h->d_gbm + (size_t)scene * 2 * (N / 32), h->d_grid);
+                       h->stream, h->cfg.grid_w, h->cfg.grid_h, h->d_gbm[h->parity] + (size_t)scene * 2 * (N / 32), h->d_grid);
     HIP_TRY(hipGetLastError());
     return fetch(h, grid, h->d_grid, N);
 }
@@ -410,10 +467,10 @@ int pp_get_refpath(pp_handle h, int scene, GlobalPoint2D* pts, int cap)
 }
 int pp_get_path(pp_handle h, int scene, int32_t* path, int cap)
 {
-    if (!h || !path || !h->d_path) return fail(PP_ERR_ARG, "no path buffer");
+    if (!h || !path || !h->d_path[0]) return fail(PP_ERR_ARG, "no path buffer");
     if (scene < 0 || scene >= h->n_scenes) return fail(PP_ERR_ARG, "scene out of range");
     if (cap > h->cfg.max_path) cap = h->cfg.max_path;
-    return fetch(h, path, h->d_path + (size_t)scene * h->cfg.max_path, (size_t)cap * sizeof(int32_t));
+    return fetch(h, path, h->d_path[h->parity] + (size_t)scene * h->cfg.max_path, (size_t)cap * sizeof(int32_t));
 }
 
 int pp_plan_tick_batch(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total,
@@ -672,9 +729,9 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes)
     case PP_BUF_MOT_POOL: p = h->d_mot; b = (size_t)h->caps.max_obs_total * sizeof(ObMotion); break;
     case PP_BUF_STATE: p = h->d_state; b = ns * sizeof(SceneState); break;
     case PP_BUF_PLAN_OUT: p = h->d_plan; b = ns * sizeof(PlanOut); break;
-    case PP_BUF_GRID_OUT: p = h->d_gout; b = ns * sizeof(GridOut); break;
-    case PP_BUF_GRID: p = h->d_gbm; b = ns * 2 * (h->grid_cells / 8); break;      // bit-packed: per scene row-major then column-major
-    case PP_BUF_PATH: p = h->d_path; b = ns * (size_t)h->max_path0 * 4; break;
+    case PP_BUF_GRID_OUT: p = h->d_gout[h->parity]; b = ns * sizeof(GridOut); break;      // the buffers of the last tick
+    case PP_BUF_GRID: p = h->d_gbm[h->parity]; b = ns * 2 * (h->grid_cells / 8); break;      // bit-packed: per scene row-major then column-major
+    case PP_BUF_PATH: p = h->d_path[h->parity]; b = ns * (size_t)h->max_path0 * 4; break;
     case PP_BUF_LANE_ATTR: p = h->d_attr; b = (size_t)h->caps.max_lane_pts_total; break;
     case PP_BUF_ORDER: p = h->d_order; b = ns * (size_t)h->caps.order_cap * 4; break;
     default: break;

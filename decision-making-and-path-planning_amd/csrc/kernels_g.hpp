@@ -283,6 +283,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     __shared__ uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
     __shared__ uint16_t c_info[kClosedTab];    // arriving direction | run length << 4 of the cell in the same slot
     if ((int)blockIdx.x >= n_scenes) return;
+    __builtin_amdgcn_s_setprio(3);             // one latency-bound wave per scene: issue ahead of the kernels that run beside it
     const int scene = perm[blockIdx.x];        // heaviest scenes first (k_order)
 #ifdef DMPP_DEBUG_SEARCH
     const long long t_entry = clock64(); long long t_loop = t_entry;

@@ -443,3 +443,32 @@ def test_lanechange_needs_attributes(dm):
     cfg["lanechg_stage"] = 0
     pl.set_config(cfg)
     pl.tick(sync=True)              # the rule tree switched off: no attributes needed
+
+
+# ---- ticks enqueued back to back (no host sync in between): the pipelined three-stream tick -----------------
+@pytest.mark.parametrize("n,grid,n_obs", [(320, 128, 24), (64, 128, 24), (300, 512, 64)])
+def test_back_to_back_ticks_match_synchronised_ones(dm, oracle, n, grid, n_obs):
+    """Dynamic obstacles, replanning every tick, 9 ticks without a host sync: the front of tick t+1 and the scoring of
+    tick t overlap the search (double-buffered by tick parity).  The final state, plan and grid results must be those
+    of the oracle ticking one tick at a time; the device is also run once more with a sync after every tick."""
+    cfg = dm.default_config(grid)
+    cfg["dynamic_obstacles"] = 1
+    cfg["force_replan"] = 1
+    sc = dm.gen_scenes(cfg, 7000, n, n_obs, junction_every=8)
+    ticks = 9
+    st_o = sc["state"].copy()
+    for _ in range(ticks):
+        plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st_o, n_threads=8)
+    for synced in (False, True):
+        pl = dm.Planner(cfg, device=0, max_scenes=n, max_obs_total=n * n_obs)
+        pl.set_scenes(sc)
+        pl.set_state(sc["state"])
+        for _ in range(ticks):
+            pl.tick(sync=synced)
+        pl.sync()
+        res = (pl.get_plan(), pl.get_state(), pl.get_grid_out(), plan_o, st_o, gout_o, None)
+        _assert_tick(res, f"synced={synced}")
+        g = pl.get_grid(3)
+        obs = oracle.effective_obstacles(cfg, sc["obs_pool"][3 * n_obs:4 * n_obs], sc["mot_pool"][3 * n_obs:4 * n_obs], ticks - 1)
+        assert np.array_equal(g, oracle.rasterise(cfg, (0.0, 0.0), obs))       # the bitmaps of the LAST tick
+        pl.close()

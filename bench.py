@@ -50,8 +50,8 @@ def algorithmic_bytes(cfg, n_obs):
         "k_effective_obstacles": 2 * 24 * n_obs,
         "k_decision": 480 * 24 + 24 * n_obs + 6 * 48 + 120 * 16,
         "k_planning": b_r,
-        "k_rasterise": W * H + 24 * n_obs,           # one u8 write per cell
-        "k_search": W * H + 3200,                    # one u8 read per cell + the path out
+        "k_rasterise": W * H + 24 * n_obs,           # one write per cell (the device writes it bit-packed, twice: W*H/4 bytes)
+        "k_search": W * H + 3200,                    # one read per cell + the path out (read bit-packed: W*H/4 bytes)
         "k_score": 24 * n_obs + 3200 + 3200,
     }
     return b_r, b_g, per_kernel
@@ -211,7 +211,8 @@ def main():
             "kernel_ms_avg": {k: (v[0] / max(v[1], 1)) for k, v in kms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": per_kernel[dom] * n, "avg_launch_ms": avg_ms},
+                         "algorithmic_bytes_per_launch": per_kernel[dom] * n, "avg_launch_ms": avg_ms,
+                         "note": "algorithmic bytes per SURVEY 8(d): one byte per grid cell + the path; the kernel reads the grid bit-packed, see traffic"},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -81,8 +81,18 @@ PlannerConfig = _dt([("ROAD_FARAIM_MAX", f8), ("ROAD_FARAIM_MIN", f8), ("PRE_INT
 PlannerCaps = _dt([("max_scenes", i4), ("max_obs_total", i4), ("max_lane_pts_total", i4), ("max_ref_pts_total", i4),
                    ("order_cap", i4), ("_pad", i4)])
 
+MapLane = _dt([("point_off", i4), ("n_points", i4), ("lane_sum", i4), ("_pad", i4)])
+MapJunction = _dt([("last_road", i4), ("next_road", i4), ("last_lane", i4), ("next_lane", i4), ("point_off", i4), ("n_points", i4)])
+
 _SIZEOF_ORDER = [PlannerConfig, PlannerCaps, SceneIn, SceneState, PlanOut, GridOut, ObPoint, ObMotion, Path_Obs,
-                 LocationOut, DecisionOut, LaneView, PlanningOut, PlanningStatus, AimPoint]
+                 LocationOut, DecisionOut, LaneView, PlanningOut, PlanningStatus, AimPoint, MapLane, MapJunction]
+
+
+class MapDesc(C.Structure):          # include/dmpp_types.h: the map store handed to pp_set_map
+    _fields_ = [("n_roads", C.c_int32), ("n_lanes", C.c_int32), ("n_points", C.c_int32), ("n_junctions", C.c_int32),
+                ("n_jpoints", C.c_int32), ("_pad", C.c_int32), ("road_first_lane", C.c_void_p), ("lanes", C.c_void_p),
+                ("points", C.c_void_p), ("lanechg_attribute", C.c_void_p), ("lane_width_cm", C.c_void_p),
+                ("junctions", C.c_void_p), ("jpoints", C.c_void_p)]
 
 
 
@@ -120,6 +130,9 @@ def load_library(path=None):
     lib.pp_set_config.argtypes = [vp, vp]
     lib.pp_set_scenes.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, vp, ci]
     lib.pp_set_n_scenes.argtypes = [vp, ci]
+    lib.pp_set_map.argtypes = [vp, vp]
+    lib.pp_set_egos.argtypes = [vp, ci, vp, vp, vp, ci]
+    lib.pp_get_scene_in.argtypes = [vp, vp, ci]
     lib.pp_set_state.argtypes = [vp, vp, ci]
     lib.pp_plan_tick.argtypes = [vp]
     lib.pp_sync.argtypes = [vp]
@@ -144,6 +157,8 @@ def load_library(path=None):
     lib.pp_device_ptr.restype = vp
     lib.pp_stream.argtypes = [vp]
     lib.pp_stream.restype = vp
+    if lib.pp_sizeof(17) != C.sizeof(MapDesc):
+        raise PlannerError(f"ABI mismatch for MapDesc: C {lib.pp_sizeof(17)} B, binding {C.sizeof(MapDesc)} B")
     for which, dt in enumerate(_SIZEOF_ORDER):
         if lib.pp_sizeof(which) != dt.itemsize:
             raise PlannerError(f"ABI mismatch for struct #{which}: C {lib.pp_sizeof(which)} B, binding {dt.itemsize} B")
@@ -228,6 +243,30 @@ class Planner:
                                       _ptr(sc["ref_pool"]), len(sc["ref_pool"]), _ptr(sc["obs_pool"]),
                                       _ptr(sc["mot_pool"]) if with_motion else None, n * sc["n_obs"]))
         self.n = n
+
+    def set_map(self, m):
+        """Resident map store (pp_set_map). `m`: dict with road_first_lane (int32, n_roads + 1), lanes (MapLane),
+        points (GlobalPoint3D), lanechg_attribute (uint8), lane_width_cm (uint16), junctions (MapJunction),
+        jpoints (GlobalPoint2D)."""
+        keep = {k: np.ascontiguousarray(m[k]) for k in ("road_first_lane", "lanes", "points", "lanechg_attribute", "lane_width_cm",
+                                                        "junctions", "jpoints")}
+        d = MapDesc(len(keep["road_first_lane"]) - 1, len(keep["lanes"]), len(keep["points"]), len(keep["junctions"]),
+                    len(keep["jpoints"]), 0, *[_ptr(keep[k]) if len(keep[k]) else None for k in
+                                               ("road_first_lane", "lanes", "points", "lanechg_attribute", "lane_width_cm",
+                                                "junctions", "jpoints")])
+        _check(self.lib.pp_set_map(self.h, C.addressof(d)))
+
+    def set_egos(self, sc, with_motion=True):
+        """Scenes on the resident map (pp_set_egos): lane views and junction slices are derived on the device."""
+        n = len(sc["scene_in"])
+        _check(self.lib.pp_set_egos(self.h, n, _ptr(sc["scene_in"]), _ptr(sc["obs_pool"]),
+                                    _ptr(sc["mot_pool"]) if with_motion else None, n * sc["n_obs"]))
+        self.n = n
+
+    def get_scene_in(self):
+        out = np.zeros(self.n, SceneIn)
+        _check(self.lib.pp_get_scene_in(self.h, _ptr(out), self.n))
+        return out
 
     def set_state(self, state):
         _check(self.lib.pp_set_state(self.h, _ptr(state), len(state)))

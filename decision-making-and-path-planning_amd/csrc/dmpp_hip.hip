@@ -55,6 +55,9 @@ struct pp_planner {
     hipEvent_t ev_raster = nullptr;
     bool score_recorded[2] = { false, false }, search_recorded[2] = { false, false }, front_recorded = false, front_unjoined = false;
     int parity = 0;              // buffers of the last tick
+    // map store (pp_set_map): lane / junction tables; the point pools are d_lane / d_attr / d_ref
+    int32_t* d_map_first = nullptr; MapLane* d_map_lanes = nullptr; uint16_t* d_map_width = nullptr; MapJunction* d_map_junc = nullptr;
+    int* d_map_bad = nullptr; int map_roads = 0, map_lanes = 0, map_junctions = 0; bool have_map = false;
     // op scratch (stand-alone operators)
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
     // profiling
@@ -246,7 +249,7 @@ int pp_destroy(pp_handle h)
     if (h->stream_s) (void)hipStreamSynchronize(h->stream_s);
     void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now[0], h->d_obs_now[1], h->d_state, h->d_plan,
                      h->d_gout[0], h->d_gout[1], h->d_dec_ref, h->d_grid, h->d_pinfo, h->d_closed, h->d_order, h->d_path[0], h->d_path[1],
-                     h->d_gbm[0], h->d_gbm[1], h->d_perm, h->d_scratch };
+                     h->d_gbm[0], h->d_gbm[1], h->d_perm, h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int q = 0; q < 2; q++) { if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]); if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]); }
     if (h->ev_raster) (void)hipEventDestroy(h->ev_raster);
@@ -300,6 +303,91 @@ int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoin
     HIP_TRY(hipStreamSynchronize(h->stream));     // the caller may reuse its buffers
     h->n_scenes = n_scenes;
     return PP_OK;
+}
+
+static int fetch(pp_handle h, void* dst, const void* src, size_t bytes);
+
+int pp_set_map(pp_handle h, const MapDesc* m)
+{
+    if (!h || !m) return fail(PP_ERR_ARG, "null argument");
+    if (m->n_roads < 0 || m->n_lanes < 0 || m->n_points < 0 || m->n_junctions < 0 || m->n_jpoints < 0) return fail(PP_ERR_ARG, "negative size");
+    if (m->n_points > h->caps.max_lane_pts_total || m->n_jpoints > h->caps.max_ref_pts_total)
+        return fail(PP_ERR_CAPACITY, "map larger than caps.max_lane_pts_total / max_ref_pts_total");
+    if ((m->n_lanes && (!m->road_first_lane || !m->lanes)) || (m->n_points && (!m->points || !m->lanechg_attribute || !m->lane_width_cm)) ||
+        (m->n_junctions && !m->junctions) || (m->n_jpoints && !m->jpoints)) return fail(PP_ERR_ARG, "null map array");
+    // the tables are host arrays: every slice is checked here, so that no scene can index outside the pools
+    if (m->n_roads && (m->road_first_lane[0] != 0 || m->road_first_lane[m->n_roads] != m->n_lanes)) return fail(PP_ERR_ARG, "road_first_lane must run from 0 to n_lanes");
+    for (int r = 0; r < m->n_roads; r++) if (m->road_first_lane[r + 1] < m->road_first_lane[r]) return fail(PP_ERR_ARG, "road_first_lane must not decrease");
+    for (int l = 0; l < m->n_lanes; l++) {
+        const MapLane& L = m->lanes[l];
+        if (L.point_off < 0 || L.n_points < 0 || (long long)L.point_off + L.n_points > m->n_points) return fail(PP_ERR_ARG, "lane slice outside the point pool");
+    }
+    for (int j = 0; j < m->n_junctions; j++) {
+        const MapJunction& J = m->junctions[j];
+        if (J.point_off < 0 || J.n_points < 0 || (long long)J.point_off + J.n_points > m->n_jpoints) return fail(PP_ERR_ARG, "junction slice outside the junction point pool");
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    { int r = join_score(h); if (r) return r; }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    void* old[] = { h->d_map_first, h->d_map_lanes, h->d_map_junc };
+    for (void* b : old) if (b) (void)hipFree(b);
+    h->d_map_first = nullptr; h->d_map_lanes = nullptr; h->d_map_junc = nullptr; h->have_map = false;
+    int r;
+    if ((r = dmalloc(&h->d_map_first, (size_t)m->n_roads + 1))) return r;
+    if ((r = dmalloc(&h->d_map_lanes, (size_t)(m->n_lanes > 0 ? m->n_lanes : 1)))) return r;
+    if ((r = dmalloc(&h->d_map_junc, (size_t)(m->n_junctions > 0 ? m->n_junctions : 1)))) return r;
+    if (!h->d_map_width && (r = dmalloc(&h->d_map_width, (size_t)h->caps.max_lane_pts_total + 1))) return r;
+    if (!h->d_map_bad && (r = dmalloc(&h->d_map_bad, (size_t)1))) return r;
+    if (m->n_roads) HIP_TRY(hipMemcpyAsync(h->d_map_first, m->road_first_lane, ((size_t)m->n_roads + 1) * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    else HIP_TRY(hipMemsetAsync(h->d_map_first, 0, sizeof(int32_t), h->stream));
+    if (m->n_lanes) HIP_TRY(hipMemcpyAsync(h->d_map_lanes, m->lanes, (size_t)m->n_lanes * sizeof(MapLane), hipMemcpyHostToDevice, h->stream));
+    if (m->n_junctions) HIP_TRY(hipMemcpyAsync(h->d_map_junc, m->junctions, (size_t)m->n_junctions * sizeof(MapJunction), hipMemcpyHostToDevice, h->stream));
+    if (m->n_points) {
+        HIP_TRY(hipMemcpyAsync(h->d_lane, m->points, (size_t)m->n_points * sizeof(GlobalPoint3D), hipMemcpyDefault, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_attr, m->lanechg_attribute, (size_t)m->n_points, hipMemcpyDefault, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_map_width, m->lane_width_cm, (size_t)m->n_points * sizeof(uint16_t), hipMemcpyDefault, h->stream));
+    }
+    if (m->n_jpoints) HIP_TRY(hipMemcpyAsync(h->d_ref, m->jpoints, (size_t)m->n_jpoints * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->map_roads = m->n_roads; h->map_lanes = m->n_lanes; h->map_junctions = m->n_junctions;
+    h->have_map = true; h->have_attr = true;
+    return PP_OK;
+}
+
+int pp_set_egos(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total)
+{
+    if (!h || !in) return fail(PP_ERR_ARG, "null argument");
+    if (!h->have_map) return fail(PP_ERR_STATE, "pp_set_egos needs a resident map (pp_set_map)");
+    if (n_scenes < 0 || n_scenes > h->caps.max_scenes) return fail(PP_ERR_CAPACITY, "n_scenes exceeds caps.max_scenes");
+    if (n_obs_total < 0 || n_obs_total > h->caps.max_obs_total) return fail(PP_ERR_CAPACITY, "obstacle pool larger than caps.max_obs_total");
+    HIP_TRY(hipSetDevice(h->device));
+    { int r = join_score(h); if (r) return r; }
+    HIP_TRY(hipMemcpyAsync(h->d_in, in, (size_t)n_scenes * sizeof(SceneIn), hipMemcpyDefault, h->stream));
+    if (n_obs_total && obs_pool) HIP_TRY(hipMemcpyAsync(h->d_obs, obs_pool, (size_t)n_obs_total * sizeof(ObPoint), hipMemcpyDefault, h->stream));
+    h->have_motion = false;
+    if (n_obs_total && mot_pool) {
+        HIP_TRY(hipMemcpyAsync(h->d_mot, mot_pool, (size_t)n_obs_total * sizeof(ObMotion), hipMemcpyDefault, h->stream));
+        h->have_motion = true;
+    }
+    HIP_TRY(hipMemsetAsync(h->d_map_bad, 0, sizeof(int), h->stream));
+    if (n_scenes)
+        hipLaunchKernelGGL(dmpp::k_resolve_map, dim3((unsigned)((n_scenes + dmpp::kBlock - 1) / dmpp::kBlock)), dim3(dmpp::kBlock), 0, h->stream,
+                           n_scenes, h->d_in, h->map_roads, h->d_map_first, h->d_map_lanes, h->d_attr, h->d_map_width,
+                           h->map_junctions, h->d_map_junc, h->d_map_bad);
+    HIP_TRY(hipGetLastError());
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, h->d_map_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->n_scenes = n_scenes;
+    if (bad) return fail(PP_ERR_ARG, "pp_set_egos: " + std::to_string(bad) + " scene(s) name a road or lane outside the map");
+    return PP_OK;
+}
+
+int pp_get_scene_in(pp_handle h, SceneIn* out, int n)
+{
+    if (!h || !out) return fail(PP_ERR_ARG, "null argument");
+    if (n < 0 || n > h->n_scenes) return fail(PP_ERR_ARG, "n exceeds the resident scenes");
+    return fetch(h, out, h->d_in, (size_t)n * sizeof(SceneIn));
 }
 
 int pp_set_n_scenes(pp_handle h, int n_scenes)
@@ -749,6 +837,7 @@ size_t pp_sizeof(int which)
     case 6: return sizeof(ObPoint); case 7: return sizeof(ObMotion); case 8: return sizeof(Path_Obs);
     case 9: return sizeof(LocationOut); case 10: return sizeof(DecisionOut); case 11: return sizeof(LaneView);
     case 12: return sizeof(PlanningOut); case 13: return sizeof(PlanningStatus); case 14: return sizeof(AimPoint);
+    case 15: return sizeof(MapLane); case 16: return sizeof(MapJunction); case 17: return sizeof(MapDesc);
     default: return 0;
     }
 }

@@ -160,6 +160,49 @@ __device__ inline void store_path_obs(Path_Obs* dst, const SoResult& r, const Ob
 }
 
 // ---------------------------------------------------------------------------------------
+// Map store -> per-scene views.  One thread per scene does what the reference does with
+// app->planning_MapData[road-1][lane-1] / [lane-2] / [lane] (Planning.cpp:331-380, Decision.cpp:562-578) and
+// planning_InterMapData[last_road-1][next_road-1][last_lane-1][next_lane-1] (Planning.cpp:342, Decision.cpp:348):
+// it writes LaneView and the junction slice into the resident SceneIn.  bad[0] counts scenes off the map.
+__global__ void __launch_bounds__(kBlock)
+k_resolve_map(int n_scenes, SceneIn* __restrict__ in, int n_roads, const int32_t* __restrict__ road_first_lane,
+              const MapLane* __restrict__ lanes, const uint8_t* __restrict__ attr, const uint16_t* __restrict__ width_cm,
+              int n_junctions, const MapJunction* __restrict__ junctions, int* __restrict__ bad)
+{
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_scenes) return;
+    SceneIn& si = in[s];
+    const LocationOut loc = si.loc;
+    LaneView lv;
+    lv.cur_off = lv.cur_n = lv.left_off = lv.left_n = lv.right_off = lv.right_n = 0;
+    lv.lane_sum = 0; lv.lanechg_attribute = 0; lv.lane_width = 0;
+    const int road = loc.road_num, lane = loc.lane_num;
+    bool ok = road >= 1 && road <= n_roads;
+    int L0 = 0, L1 = 0;
+    if (ok) { L0 = road_first_lane[road - 1]; L1 = road_first_lane[road]; ok = lane >= 1 && lane <= L1 - L0; }
+    if (ok) {
+        const MapLane cur = lanes[L0 + lane - 1];
+        lv.cur_off = cur.point_off; lv.cur_n = cur.n_points; lv.lane_sum = cur.lane_sum;
+        if (lane > 1) { const MapLane l = lanes[L0 + lane - 2]; lv.left_off = l.point_off; lv.left_n = l.n_points; }            // Planning.cpp:359-368
+        if (lane < cur.lane_sum && L0 + lane < L1) { const MapLane r = lanes[L0 + lane]; lv.right_off = r.point_off; lv.right_n = r.n_points; }   // :371-380
+        const int id = clampi(loc.id[clampi(lane - 1, 0, DMPP_LANESUM - 1)], 0, max(cur.n_points - 1, 0));
+        if (cur.n_points > 0) {
+            lv.lanechg_attribute = attr[cur.point_off + id];                        // Decision.cpp:566
+            lv.lane_width = (double)width_cm[cur.point_off + id] / 100.0;           // Decision.cpp:578
+        }
+    } else atomicAdd(bad, 1);
+    si.lanes = lv;
+    int roff = 0, rn = 0;
+    for (int j = 0; j < n_junctions; j++) {
+        const MapJunction q = junctions[j];
+        if (q.last_road == loc.last_roadnum && q.next_road == loc.next_roadnum && q.last_lane == loc.last_lanenum && q.next_lane == loc.next_lanenum) {
+            roff = q.point_off; rn = q.n_points; break;
+        }
+    }
+    si.ref_off = roff; si.ref_n = rn;
+}
+
+// ---------------------------------------------------------------------------------------
 // Lane-change rule tree of CDecision::BehaviorDecision, Decision.cpp:1017-1772, run by one thread per scene
 // on the corridor distances k_decision has just produced.  `rem` holds the remaining-length tests (see
 // k_decision).  The tree's leaves come in three shapes, named here:

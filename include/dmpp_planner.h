@@ -80,6 +80,21 @@ int  pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in,
                    const GlobalPoint2D* ref_pool, int n_ref_pts,
                    const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total);
 int  pp_set_state(pp_handle h, const SceneState* state, int n_scenes);
+/* Map store: the whole map once, shared by every scene of the handle - replaces the
+ * app->planning_MapData / planning_InterMapData members the threads index (Planning.cpp:331-356,
+ * Decision.cpp:346-348,562-578).  Needs caps.max_lane_pts_total >= map->n_points and
+ * caps.max_ref_pts_total >= map->n_jpoints.  Host or device pointers. */
+int  pp_set_map(pp_handle h, const MapDesc* map);
+/* Scenes on the resident map: SceneIn.lanes and SceneIn.ref_off / ref_n are IGNORED on input and derived on the
+ * device from loc.road_num / lane_num / id[] (current, left, right lane; lane_sum; lanechg_attribute and
+ * lane_width at the ego point) and from loc.last_roadnum / next_roadnum / last_lanenum / next_lanenum (the
+ * junction polyline; none -> empty).  A road or lane outside the map is an error (the reference would index
+ * out of its vectors). */
+int  pp_set_egos(pp_handle h, int n_scenes, const SceneIn* in,
+                 const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total);
+/* The resident SceneIn records (after pp_set_egos: with the derived lane views). */
+int  pp_get_scene_in(pp_handle h, SceneIn* out, int n_scenes);
+
 /* One Decision+Planning(+grid) tick for every resident scene: the bodies of
  * Decision.cpp:172-205 and Planning.cpp:114-223.  Asynchronous on the handle's stream. */
 int  pp_plan_tick(pp_handle h);

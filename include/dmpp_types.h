@@ -153,6 +153,32 @@ typedef struct SceneIn {
     GlobalPoint2D goal;       /* goal position, world */
 } SceneIn;
 
+/* ---- map store ------------------------------------------------------
+ * planning_MapData[road][lane][id] / decision_MapData (Planning.cpp:331-356; Decision.cpp:562-578) and
+ * planning_InterMapData[last_road][next_road][last_lane][next_lane][id] (Planning.cpp:342; Decision.cpp:348)
+ * flattened: one point pool shared by every scene, structure-of-arrays for the per-point attributes, a lane
+ * table indexed through the roads' first-lane offsets, and a junction table.  Roads and lanes are 1-based as
+ * in the reference; lane l of road r is lanes[road_first_lane[r-1] + l-1]. */
+typedef struct MapLane {
+    int32_t point_off, n_points;   /* points [point_off, point_off + n_points) of the point pool        */
+    int32_t lane_sum;              /* [road][lane][0].lane_sum                       Planning.cpp:331    */
+    int32_t _pad;
+} MapLane;
+typedef struct MapJunction {
+    int32_t last_road, next_road, last_lane, next_lane;   /* the four indices of planning_InterMapData, 1-based */
+    int32_t point_off, n_points;   /* slice of the junction point pool                                   */
+} MapJunction;
+typedef struct MapDesc {
+    int32_t n_roads, n_lanes, n_points, n_junctions, n_jpoints, _pad;
+    const int32_t*       road_first_lane;     /* n_roads + 1 entries                                        */
+    const MapLane*       lanes;               /* n_lanes                                                    */
+    const GlobalPoint3D* points;              /* n_points: global_point                                     */
+    const uint8_t*       lanechg_attribute;   /* n_points: 0 none, 1 left, 2 right, 3 both  Decision.cpp:566 */
+    const uint16_t*      lane_width_cm;       /* n_points: centimetres                      Decision.cpp:578 */
+    const MapJunction*   junctions;           /* n_junctions                                                */
+    const GlobalPoint2D* jpoints;             /* n_jpoints: junction polylines                              */
+} MapDesc;
+
 /* ---- grid-engine result (rows G2,G3) ---------------------------------------------- */
 #define DMPP_G_FOUND      0
 #define DMPP_G_NO_PATH    1   /* open set exhausted */

@@ -472,3 +472,53 @@ def test_back_to_back_ticks_match_synchronised_ones(dm, oracle, n, grid, n_obs):
         obs = oracle.effective_obstacles(cfg, sc["obs_pool"][3 * n_obs:4 * n_obs], sc["mot_pool"][3 * n_obs:4 * n_obs], ticks - 1)
         assert np.array_equal(g, oracle.rasterise(cfg, (0.0, 0.0), obs))       # the bitmaps of the LAST tick
         pl.close()
+
+
+# ---- map store: one resident map, lane views derived on the device ---------------------
+def test_map_store_views_and_ticks(dm, oracle):
+    import map_scenes as ms
+    cfg = dm.default_config(128)
+    m = ms.build_map(dm, n_roads=5)
+    n, n_obs = 96, 16
+    sc = ms.make_egos(dm, cfg, m, n, n_obs)
+    pl = dm.Planner(cfg, device=0, max_scenes=n, max_obs_total=n * n_obs, max_lane_pts_total=len(m["points"]),
+                    max_ref_pts_total=max(len(m["jpoints"]), 1))
+    pl.set_map(m)
+    pl.set_egos(sc)
+    want = ms.resolve(dm, m, sc["scene_in"])
+    got = pl.get_scene_in()
+    assert not compare(got, want, "scene_in")                   # lane views, attribute / width at the ego point, junction slices
+    assert set(np.unique(want["loc"]["pos"])) == {0, 1, 2} and (want["lanes"]["left_n"] == 0).any() and (want["lanes"]["right_n"] == 0).any()
+    # the same scenes through the oracle, which indexes the shared pools with the views derived above
+    sc_o = dict(sc)
+    sc_o["scene_in"] = want
+    st_o = sc["state"].copy()
+    pl.set_state(sc["state"])
+    for t in range(6):
+        pl.tick(sync=True)
+        plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc_o, st_o, n_threads=8)
+        _assert_tick((pl.get_plan(), pl.get_state(), pl.get_grid_out(), plan_o, st_o, gout_o, None), f"tick {t}")
+    seen = set(np.unique(st_o["z_behavior"]).tolist())
+    assert 1 in seen and len(seen) >= 2                         # more than lane keeping happens on this map
+
+
+def test_map_store_errors(dm):
+    import map_scenes as ms
+    cfg = dm.default_config(128)
+    m = ms.build_map(dm, n_roads=3)
+    sc = ms.make_egos(dm, cfg, m, 4, 4)
+    pl = dm.Planner(cfg, device=0, max_scenes=4, max_obs_total=16, max_lane_pts_total=len(m["points"]), max_ref_pts_total=len(m["jpoints"]))
+    with pytest.raises(dm.PlannerError, match="resident map"):
+        pl.set_egos(sc)
+    bad = dict(m)
+    bad["lanes"] = m["lanes"].copy()
+    bad["lanes"]["n_points"][2] = len(m["points"])              # slice runs past the point pool
+    with pytest.raises(dm.PlannerError, match="outside the point pool"):
+        pl.set_map(bad)
+    pl.set_map(m)
+    sc["scene_in"]["loc"]["road_num"][1] = 9                    # no such road: the reference would index out of its vectors
+    with pytest.raises(dm.PlannerError, match="outside the map"):
+        pl.set_egos(sc)
+    small = dm.Planner(cfg, device=0, max_scenes=4, max_obs_total=16, max_lane_pts_total=100, max_ref_pts_total=10)
+    with pytest.raises(dm.PlannerError, match="larger than caps"):
+        small.set_map(m)

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <cstdlib>
 #include <vector>
 #include <new>
 #include "../../include/dmpp_planner.h"
@@ -98,7 +99,7 @@ hipEvent_t get_event(pp_planner* h)
     return e;
 }
 
-constexpr int kPipelineMinScenes = 256;      // batches at least this large run k_score beside the next tick's search
+int kPipelineMinScenes = 256;                // batches at least this large run the three chains on three streams (env DMPP_PIPELINE_MIN)
 
 // Everything a tick started is ordered before whatever the handle's stream does next.
 int join_score(pp_planner* h)
@@ -138,8 +139,17 @@ int setup_grid_launch(pp_planner* h)
     if (!c.grid_stage) return PP_OK;
     const size_t N = (size_t)c.grid_w * c.grid_h;
     // rasterise: bands of <= 65536 cells (8 KiB of LDS bits), whole rows
-    int band = (65536 / c.grid_w) / 32 * 32; if (band < 32) band = 32; if (band > c.grid_h) band = c.grid_h;   // whole 32-row words
+    // rasterise: bands of 128 whole rows (measured best at 512 and at 2048 columns: 16-byte pieces of the column-major
+    // bitmap per column and band, 4 - 16 bands per scene), both orientations of a band in LDS (32 bytes per column)
+    int band = 128;
+    if (const char* e = std::getenv("DMPP_RASTER_BAND_ROWS")) band = std::atoi(e) / 32 * 32;       // tuning knob
+    if (band < 32) band = 32; if (band > c.grid_h) band = c.grid_h;
     h->raster_band_rows = band;
+    {   // both LDS bit bands of k_rasterise (row- and column-major) + its 10 KB of static tables
+        const size_t lds = 2 * ((size_t)band * c.grid_w / 8);
+        if (lds + 12288 > 48u * 1024u)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_rasterise), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     // search: word summaries of both bitmap views always in LDS; the bitmaps too when they fit, else in HBM
     const size_t bm_bytes = 2 * (N / 8);              // row-major + column-major obstacle bits
     const size_t ww = (size_t)c.grid_w / 32, hw = (size_t)c.grid_h / 32;
@@ -182,6 +192,7 @@ const char* pp_last_error(void) { return g_err.c_str(); }
 int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_handle* out)
 {
     if (!out || !caps) return fail(PP_ERR_ARG, "null argument");
+    if (const char* e = std::getenv("DMPP_PIPELINE_MIN")) kPipelineMinScenes = std::atoi(e);      // tuning knob: 0 = always, large = never
     *out = nullptr;
     int r = check_cfg(cfg); if (r) return r;
     if (caps->max_scenes <= 0) return fail(PP_ERR_ARG, "max_scenes must be positive");

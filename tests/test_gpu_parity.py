@@ -522,3 +522,31 @@ def test_map_store_errors(dm):
     small = dm.Planner(cfg, device=0, max_scenes=4, max_obs_total=16, max_lane_pts_total=100, max_ref_pts_total=10)
     with pytest.raises(dm.PlannerError, match="larger than caps"):
         small.set_map(m)
+
+
+def test_back_to_back_ticks_across_config_changes(dm, oracle):
+    """The grid stage switched off and on again between un-synchronised ticks (three-stream form -> one stream -> back),
+    and the scene inputs replaced in between: every hand-over between the chains must still be ordered."""
+    n, n_obs = 288, 16
+    cfg = dm.default_config(128)
+    cfg["dynamic_obstacles"] = 1
+    cfg["force_replan"] = 1
+    sc = dm.gen_scenes(cfg, 8100, n, n_obs, junction_every=8)
+    pl = dm.Planner(cfg, device=0, max_scenes=n, max_obs_total=n * n_obs)
+    pl.set_scenes(sc)
+    pl.set_state(sc["state"])
+    st_o = sc["state"].copy()
+    plan_o = gout_o = None
+    schedule = [1, 1, 1, 0, 0, 1, 1, 0, 1, 1]
+    for t, g in enumerate(schedule):
+        cfg["grid_stage"] = g
+        pl.set_config(cfg)
+        if t == 5:
+            move_ego(sc, 3)
+            pl.set_scenes(sc)
+        pl.tick()
+        plan_o, go, _ = oracle.plan_tick_batch(cfg, sc, st_o, n_threads=8, want_grid=bool(g))
+        if g:
+            gout_o = go
+    pl.sync()
+    _assert_tick((pl.get_plan(), pl.get_state(), pl.get_grid_out(), plan_o, st_o, gout_o, None), "after the schedule")

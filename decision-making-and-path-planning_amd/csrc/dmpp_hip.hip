@@ -99,6 +99,7 @@ hipEvent_t get_event(pp_planner* h)
     return e;
 }
 
+constexpr int kSearchSlots = 512;            // search waves resident at once on 256 CUs (80 KB of LDS each)
 int kPipelineMinScenes = 256;                // batches at least this large run the three chains on three streams (env DMPP_PIPELINE_MIN)
 
 // Everything a tick started is ordered before whatever the handle's stream does next.
@@ -477,14 +478,15 @@ int pp_plan_tick(pp_handle h)
         if (sf != sm) HIP_TRY(hipStreamWaitEvent(sm, h->ev_raster, 0));
         {
             Timed t(h, PP_K_SEARCH, sm);
-            (void)hipMemsetAsync(h->d_closed, 0, (size_t)n * ((size_t)c.grid_w * c.grid_h / 8), sm);   // the closed bit sets
-            hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_gout[p ^ 1], h->d_perm);   // by last tick's cost
+            // heaviest scenes first (by last tick's cost) - pointless while every scene is resident at once (2 waves per CU)
+            const int32_t* perm = n > kSearchSlots ? h->d_perm : nullptr;
+            if (perm) hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_gout[p ^ 1], h->d_perm);
             if (h->search_gbm)
-                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap, h->d_perm, h->d_in,
+                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap, perm, h->d_in,
                                    h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p]);
             else
                 hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap,
-                                   h->d_perm, h->d_in, h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p]);
+                                   perm, h->d_in, h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p]);
         }
         h->search_recorded[p] = piped;                   // (one-stream mode: stream order is enough, no events on the latency path)
         if (piped) { HIP_TRY(hipEventRecord(h->ev_search[p], sm)); HIP_TRY(hipStreamWaitEvent(ss, h->ev_search[p], 0)); }

@@ -284,7 +284,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     __shared__ uint16_t c_info[kClosedTab];    // arriving direction | run length << 4 of the cell in the same slot
     if ((int)blockIdx.x >= n_scenes) return;
     __builtin_amdgcn_s_setprio(3);             // one latency-bound wave per scene: issue ahead of the kernels that run beside it
-    const int scene = perm[blockIdx.x];        // heaviest scenes first (k_order)
+    const int scene = perm ? perm[blockIdx.x] : (int)blockIdx.x;      // heaviest scenes first (k_order) when they do not all fit at once
 #ifdef DMPP_DEBUG_SEARCH
     const long long t_entry = clock64(); long long t_loop = t_entry;
 #endif
@@ -300,7 +300,12 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     uint32_t* bmT = bm + (N >> 5);
     const SceneIn& si = in[scene];
     GridOut& go = gout[scene];
-    uint32_t* closed = gclosed + (size_t)scene * (N >> 5);        // zeroed by the host before the launch
+    uint32_t* closed = gclosed + (size_t)scene * (N >> 5);
+    {   // this scene's closed bit set starts empty (16 bytes per lane; done with before the first atomicOr, see the wait below)
+        uint4* c4 = reinterpret_cast<uint4*>(closed);
+        const uint4 z = { 0u, 0u, 0u, 0u };
+        for (int i = lane; i < (N >> 7); i += DMPP_WAVE) c4[i] = z;
+    }
     uint16_t* pin = pinfo + (size_t)scene * N;
     int32_t* order = orders ? orders + (size_t)scene * order_cap : nullptr;
     int32_t* path = paths + (size_t)scene * c.max_path;
@@ -317,8 +322,8 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src4 + c0 + lane),
                                              (__attribute__((address_space(3))) void*)(dst4 + c0), 16, 0, 0);
         if (full + lane < chunks) dst4[full + lane] = src4[full + lane];
-        __builtin_amdgcn_s_waitcnt(0);
     }
+    __builtin_amdgcn_s_waitcnt(0);             // the bitmaps have landed in LDS and the zeroes of the closed bit set in L2
     wave_sync();
 #ifdef DMPP_DEBUG_SEARCH
     const long long t_pack = clock64(); long long t_tr = t_pack, t_nz = t_pack;

@@ -99,6 +99,7 @@ hipEvent_t get_event(pp_planner* h)
     return e;
 }
 
+constexpr int kScoreWideMaxScenes = 128;     // up to here k_score runs 16 waves per scene (one scene per CU at most)
 constexpr int kSearchSlots = 512;            // search waves resident at once on 256 CUs (80 KB of LDS each)
 int kPipelineMinScenes = 256;                // batches at least this large run the three chains on three streams (env DMPP_PIPELINE_MIN)
 
@@ -176,6 +177,8 @@ int setup_grid_launch(pp_planner* h)
             h->search_gbm = true; h->search_lds = (int)nz_bytes;
         }
     }
+    if (sizeof(dmpp::ScoreShared<16>) > 48u * 1024u)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_score<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(dmpp::ScoreShared<16>));
     if (!h->d_perm) { int r = dmalloc(&h->d_perm, (size_t)h->caps.max_scenes); if (r) return r; }
     for (int q = 0; q < 2; q++) if (!h->d_gbm[q]) {   // bit-packed occupancy, row- and column-major: written by k_rasterise, read by k_search
         int r = dmalloc(&h->d_gbm[q], (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
@@ -492,8 +495,12 @@ int pp_plan_tick(pp_handle h)
         if (piped) { HIP_TRY(hipEventRecord(h->ev_search[p], sm)); HIP_TRY(hipStreamWaitEvent(ss, h->ev_search[p], 0)); }
         {
             Timed t(h, PP_K_SCORE, ss);
-            hipLaunchKernelGGL(dmpp::k_score, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::ScoreShared), ss, c, n, h->d_in, obs_now,
-                               h->d_path[p], h->d_gout[p]);
+            if (n <= kScoreWideMaxScenes)     // few scenes: sixteen waves per scene (17 candidates in two rounds)
+                hipLaunchKernelGGL(dmpp::k_score<16>, dim3(n), dim3(16 * DMPP_WAVE), sizeof(dmpp::ScoreShared<16>), ss, c, n, h->d_in, obs_now,
+                                   h->d_path[p], h->d_gout[p]);
+            else
+                hipLaunchKernelGGL(dmpp::k_score<4>, dim3(n), dim3(4 * DMPP_WAVE), sizeof(dmpp::ScoreShared<4>), ss, c, n, h->d_in, obs_now,
+                                   h->d_path[p], h->d_gout[p]);
         }
         h->score_recorded[p] = piped;
         if (piped) HIP_TRY(hipEventRecord(h->ev_score[p], ss));

@@ -778,9 +778,12 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
 
 // ---------------------------------------------------------------------------------------
 // G3.  256 threads = 4 waves per scene; wave w scores candidates w, w+4, ...
+// NW waves per scene score the candidates NW at a time: 4 for batches (four scenes per CU), 16 for the few scenes of a
+// latency-bound tick (17 candidates in 2 rounds instead of 5).
+template <int NW>
 struct ScoreShared {
-    GlobalPoint2D cand[4][DMPP_PATH_POINTS];
-    double seg[4][DMPP_PATH_POINTS];         // |P_i - P_{i+1}| of the wave's current candidate
+    GlobalPoint2D cand[NW][DMPP_PATH_POINTS];
+    double seg[NW][DMPP_PATH_POINTS];        // |P_i - P_{i+1}| of the wave's current candidate
     GlobalPoint2D pts[DMPP_PATH_POINTS];     // grid-path prefix in metres (lookahead_cells+1 <= 200)
     double cum[DMPP_PATH_POINTS];
     double rx[kMaxObsLds], ry[kMaxObsLds], rr[kMaxObsLds], rt2[kMaxObsLds];   // obstacles that can matter: x, y, radius, cutoff^2
@@ -796,12 +799,14 @@ __device__ __forceinline__ double wave_tree_sum(double acc)
     return acc;
 }
 
-__global__ void __launch_bounds__(kBlock)
+template <int NW>
+__global__ void __launch_bounds__(NW * DMPP_WAVE)
 k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObPoint* __restrict__ obs_now,
         const int32_t* __restrict__ paths, GridOut* __restrict__ gout)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    ScoreShared& sh = *reinterpret_cast<ScoreShared*>(smem_raw);
+    ScoreShared<NW>& sh = *reinterpret_cast<ScoreShared<NW>*>(smem_raw);
+    constexpr int kThreads = NW * DMPP_WAVE;
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -828,7 +833,7 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
             GlobalPoint2D P0 = { si.grid_origin.x + ((double)(p0 % W) + 0.5) * c.cell, si.grid_origin.y + ((double)(p0 / W) + 0.5) * c.cell };
             thT = GetRoadAngle(c, P0, T);
         }
-        for (int i = tid; i <= a; i += kBlock) {
+        for (int i = tid; i <= a; i += kThreads) {
             const int pc = path[i];
             sh.pts[i].x = si.grid_origin.x + ((double)(pc % W) + 0.5) * c.cell;
             sh.pts[i].y = si.grid_origin.y + ((double)(pc / W) + 0.5) * c.cell;
@@ -874,7 +879,7 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
     }
     const bool culled = m <= kMaxObsLds;          // longer lists are read from HBM without culling
     if (culled) {
-        for (int j = tid; j < m; j += kBlock) {
+        for (int j = tid; j < m; j += kThreads) {
             const ObPoint o = gobs[j];
             const double thr = (double)o.radius + half_w + c.d_safe;
             if (o.x >= X0 - thr && o.x <= X1 + thr && o.y >= Y0 - thr && o.y <= Y1 + thr) {
@@ -887,7 +892,7 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
     const int n_rel = culled ? sh.n_rel : m;
     GlobalPoint2D* cand = sh.cand[wave];
     double* seg = sh.seg[wave];
-    for (int k = wave; k < nc; k += 4) {
+    for (int k = wave; k < nc; k += NW) {
         double off = 0;
         if (k < nl) {
             const Bezier bz = lattice_curve(k, off);

@@ -550,3 +550,21 @@ def test_back_to_back_ticks_across_config_changes(dm, oracle):
             gout_o = go
     pl.sync()
     _assert_tick((pl.get_plan(), pl.get_state(), pl.get_grid_out(), plan_o, st_o, gout_o, None), "after the schedule")
+
+
+@pytest.mark.parametrize("gw,gh", [(96, 160), (224, 64), (32, 32), (640, 384)])
+def test_non_square_grids(dm, oracle, gw, gh):
+    """Line widths that are not a power of two (3, 7, 20 words), very small and non-square grids: the word summaries,
+    the band layout of the rasteriser and the candidate-word scans must not depend on the 512 x 512 shape."""
+    cfg = dm.default_config(gw, gh)
+    n = 48
+    sc = dm.gen_scenes(cfg, 9100, n, 12, junction_every=0)
+    # the generator spreads goals over the width: keep them inside the shorter grids
+    sc["scene_in"]["goal"]["y"] = np.clip(sc["scene_in"]["goal"]["y"], 0.0, gh * float(cfg["cell"][0]) - 0.01)
+    pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=2, order_cap=gw * gh)
+    for t, r in enumerate(res):
+        _assert_tick(r, f"{gw}x{gh} tick {t}")
+    for s_ in (0, 7, 31):
+        assert np.array_equal(pl.get_grid(s_), r[6][s_])
+    found = int((res[-1][5]["status"] == dm.G_FOUND).sum())
+    assert found >= (4 if gw > 32 else 0)

@@ -697,12 +697,24 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
                 int incl = rn;
 #pragma unroll
                 for (int sft = 1; sft < DMPP_WAVE; sft <<= 1) { const int t = __shfl_up(incl, sft, 64); if (lane >= sft) incl += t; }
+                int ec = 0, step = 0;
+                const int idx0 = kbase + incl - rn;
                 if (rn) {
-                    const int ec = (int)o_ent[j], pd = o_f2[j];
+                    const int pd = o_f2[j];
+                    ec = (int)o_ent[j];
                     const int dx = (int)((0x901Au >> (2 * pd)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * pd)) & 3u) - 1;
-                    const int step = dy * W + dx;
-                    int idx = kbase + incl - rn;
-                    for (int r = 0; r < rn && idx < keep; r++, idx++) path[keep - 1 - idx] = ec - r * step;
+                    step = dy * W + dx;
+                }
+                // short runs (diagonal jumps, hops between close jump points): the hop's lane writes its cells; long
+                // straight runs: the whole wave writes one run together
+                constexpr int kLongRun = 12;
+                if (rn && rn <= kLongRun) { int idx = idx0; for (int r = 0; r < rn && idx < keep; r++, idx++) path[keep - 1 - idx] = ec - r * step; }
+                unsigned long long lm = __ballot(rn > kLongRun);
+                while (lm) {
+                    const int src = __ffsll((long long)lm) - 1;
+                    lm &= lm - 1;
+                    const int h_ec = __shfl(ec, src, 64), h_step = __shfl(step, src, 64), h_rn = __shfl(rn, src, 64), h_idx = __shfl(idx0, src, 64);
+                    for (int r = lane; r < h_rn; r += DMPP_WAVE) if (h_idx + r < keep) path[keep - 1 - (h_idx + r)] = h_ec - r * h_step;
                 }
                 kbase += __shfl(incl, DMPP_WAVE - 1, 64);
             }

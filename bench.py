@@ -209,6 +209,10 @@ def main():
             "p50_plan_latency_ms_batch1": p50_ms,
             "search_status_counts": np.bincount(gout["status"], minlength=6).tolist(),
             "kernel_ms_avg": {k: (v[0] / max(v[1], 1)) for k, v in kms.items()},
+            # algorithmic bytes of each kernel over its own average launch time; the kernels of neighbouring
+            # ticks overlap on three streams, so these are per-kernel rates, not shares of the tick
+            "kernel_algorithmic_GBps": {k: (per_kernel[k] * n / (v[0] / max(v[1], 1) * 1e-3) / 1e9 if v[0] > 0 else 0.0)
+                                        for k, v in kms.items() if k in per_kernel},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": per_kernel[dom] * n, "avg_launch_ms": avg_ms,

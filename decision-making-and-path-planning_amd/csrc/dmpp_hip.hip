@@ -45,7 +45,7 @@ struct pp_planner {
     GlobalPoint2D* d_dec_ref = nullptr;
     // grid engine
     uint8_t* d_grid = nullptr; uint16_t* d_pinfo = nullptr; uint32_t* d_closed = nullptr;
-    int32_t* d_order = nullptr; int32_t* d_path[2] = { nullptr, nullptr }; uint32_t* d_gbm[2] = { nullptr, nullptr }; int32_t* d_perm = nullptr;
+    int32_t* d_order = nullptr; int32_t* d_path[2] = { nullptr, nullptr }; uint32_t* d_gbm[2] = { nullptr, nullptr }; int32_t* d_perm = nullptr; int32_t* d_cost = nullptr;
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
     bool search_gbm = false; int search_lds = 0; int raster_band_rows = 0;
@@ -180,6 +180,10 @@ int setup_grid_launch(pp_planner* h)
     if (sizeof(dmpp::ScoreShared<16>) > 48u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_score<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(dmpp::ScoreShared<16>));
     if (!h->d_perm) { int r = dmalloc(&h->d_perm, (size_t)h->caps.max_scenes); if (r) return r; }
+    if (!h->d_cost) {
+        int r = dmalloc(&h->d_cost, (size_t)h->caps.max_scenes); if (r) return r;
+        HIP_TRY(hipMemsetAsync(h->d_cost, 0, (size_t)h->caps.max_scenes * sizeof(int32_t), h->stream));
+    }
     for (int q = 0; q < 2; q++) if (!h->d_gbm[q]) {   // bit-packed occupancy, row- and column-major: written by k_rasterise, read by k_search
         int r = dmalloc(&h->d_gbm[q], (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
         if (r) return r;
@@ -282,7 +286,7 @@ int pp_destroy(pp_handle h)
     if (h->stream_s) (void)hipStreamSynchronize(h->stream_s);
     void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now[0], h->d_obs_now[1], h->d_state, h->d_plan,
                      h->d_gout[0], h->d_gout[1], h->d_dec_ref, h->d_grid, h->d_pinfo, h->d_closed, h->d_order, h->d_path[0], h->d_path[1],
-                     h->d_gbm[0], h->d_gbm[1], h->d_perm, h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad };
+                     h->d_gbm[0], h->d_gbm[1], h->d_perm, h->d_cost, h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int q = 0; q < 2; q++) { if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]); if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]); }
     if (h->ev_raster) (void)hipEventDestroy(h->ev_raster);
@@ -501,13 +505,13 @@ int pp_plan_tick(pp_handle h)
             Timed t(h, PP_K_SEARCH, sm);
             // heaviest scenes first (by last tick's cost) - pointless while every scene is resident at once (2 waves per CU)
             const int32_t* perm = n > kSearchSlots ? h->d_perm : nullptr;
-            if (perm) hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_gout[p ^ 1], h->d_perm);
+            if (perm) hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost, h->d_perm);
             if (h->search_gbm)
                 hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap, perm, h->d_in,
-                                   h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p]);
+                                   h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost);
             else
                 hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap,
-                                   perm, h->d_in, h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p]);
+                                   perm, h->d_in, h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost);
         }
         h->search_recorded[p] = piped;                   // (one-stream mode: stream order is enough, no events on the latency path)
         if (piped) { HIP_TRY(hipEventRecord(h->ev_search[p], sm)); HIP_TRY(hipStreamWaitEvent(ss, h->ev_search[p], 0)); }

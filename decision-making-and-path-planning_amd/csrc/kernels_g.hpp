@@ -249,30 +249,30 @@ __device__ __forceinline__ int jump_lane(const View& V, bool active, int line, i
     return run;
 }
 
-// Launch order of the scenes of k_search: heaviest first, by the cells the scene expanded on the previous tick (its
-// cost changes little from tick to tick).  One wave per scene and two waves per CU means the kernel ends with its
+// Launch order of the scenes of k_search: heaviest first, by the time the scene's search took on the previous tick (in
+// units of 16 Ki cycles, written by k_search; it changes little from tick to tick).  One wave per scene and two waves per CU means the kernel ends with its
 // slowest scene; starting that scene first keeps it off the tail.  Counting sort into 64 cost classes, one block.
 constexpr int kOrderBlock = 1024, kOrderClasses = 64;
 __global__ void __launch_bounds__(kOrderBlock)
-k_order(int n_scenes, const GridOut* __restrict__ gout, int32_t* __restrict__ perm)
+k_order(int n_scenes, const int32_t* __restrict__ cost, int32_t* __restrict__ perm)
 {
     __shared__ int cnt[kOrderClasses], base[kOrderClasses];
     const int tid = threadIdx.x;
     if (tid < kOrderClasses) cnt[tid] = 0;
     __syncthreads();
-    for (int s = tid; s < n_scenes; s += kOrderBlock) atomicAdd(&cnt[kOrderClasses - 1 - min(gout[s].n_expanded >> 3, kOrderClasses - 1)], 1);
+    for (int s = tid; s < n_scenes; s += kOrderBlock) atomicAdd(&cnt[kOrderClasses - 1 - min(cost[s], kOrderClasses - 1)], 1);
     __syncthreads();
     if (tid == 0) { int acc = 0; for (int k = 0; k < kOrderClasses; k++) { base[k] = acc; acc += cnt[k]; } }
     __syncthreads();
     for (int s = tid; s < n_scenes; s += kOrderBlock)
-        perm[atomicAdd(&base[kOrderClasses - 1 - min(gout[s].n_expanded >> 3, kOrderClasses - 1)], 1)] = s;
+        perm[atomicAdd(&base[kOrderClasses - 1 - min(cost[s], kOrderClasses - 1)], 1)] = s;
 }
 
 template <bool GBM>
 __global__ void __launch_bounds__(DMPP_WAVE)
 k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
          uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
-         int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps)
+         int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24
@@ -283,6 +283,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     __shared__ uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
     __shared__ uint16_t c_info[kClosedTab];    // arriving direction | run length << 4 of the cell in the same slot
     if ((int)blockIdx.x >= n_scenes) return;
+    const long long t_begin = clock64();
     __builtin_amdgcn_s_setprio(3);             // one latency-bound wave per scene: issue ahead of the kernels that run beside it
     const int scene = perm ? perm[blockIdx.x] : (int)blockIdx.x;      // heaviest scenes first (k_order) when they do not all fit at once
 #ifdef DMPP_DEBUG_SEARCH
@@ -783,6 +784,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
         bmT[sx * HW + (sy >> 5)] |= 1u << (sy & 31);
     }
     if (lane == 0) {
+        cost_out[scene] = (int32_t)((clock64() - t_begin) >> 14);          // launch-order key of the next tick (k_order)
         go.order_digest = digest; go.status = status; go.n_expanded = n_exp; go.n_pushed = n_push; go.n_rounds = n_rounds;
         go.path_len = path_len; go.path_cost = path_cost; go.start_cell = start; go.goal_cell = goal;
     }

@@ -218,14 +218,14 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
-    // The two side streams (front, score) may use 72 % of the CUs; the rest run nothing but search waves.  The search
+    // The two side streams (front, score) may use 88 % of the CUs; the rest run nothing but search waves.  The search
     // needs two 80 KB workgroups per CU and the hardware does not keep the short kernels' workgroups out of its way by
-    // queue priority alone; measured on configs[1]: 0.673 ms per tick without the mask, 0.625 with 184 of 256 CUs
-    // (176-192 is the flat optimum; 128: 0.718, 64: 1.06).  DMPP_SIDE_CUS=<n> overrides, 0 = no mask.
+    // queue priority alone; measured on configs[1] (with the time-keyed launch order): 0.596 ms per tick without the
+    // mask, 0.555 with 224-240 of 256 CUs (200: 0.572, 184: 0.582, 160: 0.654).  DMPP_SIDE_CUS=<n> overrides, 0 = no mask.
     int side_cus = 0;
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess) side_cus = prop.multiProcessorCount * 72 / 100;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) side_cus = prop.multiProcessorCount * 88 / 100;
         if (const char* e = std::getenv("DMPP_SIDE_CUS")) side_cus = std::atoi(e);
     }
     uint32_t cu_mask[32] = { 0 };

@@ -250,22 +250,31 @@ __device__ __forceinline__ int jump_lane(const View& V, bool active, int line, i
 }
 
 // Launch order of the scenes of k_search: heaviest first, by the time the scene's search took on the previous tick (in
-// units of 16 Ki cycles, written by k_search; it changes little from tick to tick).  One wave per scene and two waves per CU means the kernel ends with its
-// slowest scene; starting that scene first keeps it off the tail.  Counting sort into 64 cost classes, one block.
-constexpr int kOrderBlock = 1024, kOrderClasses = 64;
+// units of 8 Ki cycles, written by k_search; it changes little from tick to tick).  One wave per scene and two waves per CU means the kernel ends with its
+// slowest scene; starting that scene first keeps it off the tail.  Counting sort into 1024 cost classes, one block.
+constexpr int kOrderBlock = 1024, kOrderClasses = 1024, kOrderShift = 13;     // classes of 8 Ki cycles, up to 8.4 M cycles
 __global__ void __launch_bounds__(kOrderBlock)
 k_order(int n_scenes, const int32_t* __restrict__ cost, int32_t* __restrict__ perm)
 {
     __shared__ int cnt[kOrderClasses], base[kOrderClasses];
     const int tid = threadIdx.x;
-    if (tid < kOrderClasses) cnt[tid] = 0;
+    cnt[tid] = 0;
     __syncthreads();
-    for (int s = tid; s < n_scenes; s += kOrderBlock) atomicAdd(&cnt[kOrderClasses - 1 - min(cost[s], kOrderClasses - 1)], 1);
+    for (int s = tid; s < n_scenes; s += kOrderBlock) atomicAdd(&cnt[kOrderClasses - 1 - min(max(cost[s], 0), kOrderClasses - 1)], 1);
     __syncthreads();
-    if (tid == 0) { int acc = 0; for (int k = 0; k < kOrderClasses; k++) { base[k] = acc; acc += cnt[k]; } }
+    // exclusive prefix sum over the classes (heaviest class first): Hillis-Steele in LDS, one class per thread
+    base[tid] = cnt[tid];
+    __syncthreads();
+    for (int d = 1; d < kOrderClasses; d <<= 1) {
+        const int v = tid >= d ? base[tid - d] : 0;
+        __syncthreads();
+        base[tid] += v;
+        __syncthreads();
+    }
+    base[tid] -= cnt[tid];
     __syncthreads();
     for (int s = tid; s < n_scenes; s += kOrderBlock)
-        perm[atomicAdd(&base[kOrderClasses - 1 - min(cost[s], kOrderClasses - 1)], 1)] = s;
+        perm[atomicAdd(&base[kOrderClasses - 1 - min(max(cost[s], 0), kOrderClasses - 1)], 1)] = s;
 }
 
 template <bool GBM>
@@ -784,7 +793,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
         bmT[sx * HW + (sy >> 5)] |= 1u << (sy & 31);
     }
     if (lane == 0) {
-        cost_out[scene] = (int32_t)((clock64() - t_begin) >> 14);          // launch-order key of the next tick (k_order)
+        cost_out[scene] = (int32_t)min((clock64() - t_begin) >> kOrderShift, (long long)(kOrderClasses - 1));   // launch-order key of the next tick (k_order)
         go.order_digest = digest; go.status = status; go.n_expanded = n_exp; go.n_pushed = n_push; go.n_rounds = n_rounds;
         go.path_len = path_len; go.path_cost = path_cost; go.start_cell = start; go.goal_cell = goal;
     }

@@ -297,6 +297,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     const int scene = perm ? perm[blockIdx.x] : (int)blockIdx.x;      // heaviest scenes first (k_order) when they do not all fit at once
 #ifdef DMPP_DEBUG_SEARCH
     const long long t_entry = clock64(); long long t_loop = t_entry;
+    const long long w_entry = wall_clock64();          // 100 MHz, the same counter on every CU: launch timeline of the scenes
 #endif
     const int lane = threadIdx.x;
     const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5;
@@ -785,7 +786,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     }
 #ifdef DMPP_DEBUG_SEARCH
     if (lane == 0) { long long te = clock64(); int32_t* dbg = path + c.max_path - 16; dbg[0] = c_iter; dbg[1] = c_scan; dbg[2] = c_jobs; dbg[3] = c_pass; dbg[4] = c_scan;
-        dbg[5] = (int)(t_pop >> 4); dbg[6] = (int)(t_closed >> 4); dbg[7] = (int)(t_cand >> 4); dbg[8] = (int)(t_jump >> 4); dbg[9] = (int)(t_push >> 4); dbg[10] = (int)((te - t_done) >> 4); dbg[11] = (int)((te - t0) >> 4); dbg[12] = (int)((t_loop - t_entry) >> 4); dbg[13] = (int)((te - t_entry) >> 4); dbg[14] = (int)((t_pack - t_entry) >> 4); dbg[15] = (int)((t_tr - t_pack) >> 4); dbg[4] = (int)((t_nz - t_tr) >> 4); }
+        dbg[5] = (int)(t_pop >> 4); dbg[6] = (int)(t_closed >> 4); dbg[7] = (int)(t_cand >> 4); dbg[8] = (int)(t_jump >> 4); dbg[9] = (int)(t_push >> 4); dbg[10] = (int)((te - t_done) >> 4); dbg[11] = (int)((te - t0) >> 4); dbg[12] = (int)((t_loop - t_entry) >> 4); dbg[13] = (int)((te - t_entry) >> 4); dbg[14] = (int)(w_entry & 0x7FFFFFFF); dbg[15] = (int)(wall_clock64() & 0x7FFFFFFF); dbg[4] = (int)((t_nz - t_tr) >> 4); }
 #endif
     if (GBM && lane == 0 && start_was_set) {           // the bitmaps in HBM are the grid pp_get_grid returns: leave them as rasterised
         const int sx = start % W, sy = start / W;

@@ -100,23 +100,18 @@ void orc_rasterise(const PlannerConfig* c, GlobalPoint2D origin, const ObPoint* 
  *                          s = d+-2 -> jump(p,s) only if forced: the cell p + (s-d)/2 is blocked and p+s free.
  *   open set: a list in push order; an entry is (f, cell, arriving direction, run length); g is
  *             recovered as f - h(cell).
- *   step    : up to DMPP_JPS_BATCH (4) entries are taken from the open set, one after the other: each time the entry
- *             with the smallest f, among equals the most recently pushed.  An entry whose cell is already closed with
- *             a g at least as small is dropped; otherwise its cell is closed - or closed AGAIN with the smaller g, its
- *             arriving direction and run length replaced - as expansion number k (k counts every closing).  The goal
- *             is only closed (its g becomes the best cost G so far); every other cell closed in the step joins the
- *             batch, and the batch nodes, in that order, push their successors (s = 0..7), except those whose f is
- *             not below G.  Taking entries beyond the minimal f is speculation: a wave has four node slots per step
- *             and the minimal f rarely has four entries, so the slots are filled with the next best ones; a cell
- *             closed too early is simply closed again when the cheaper entry arrives (its successors follow), which
- *             keeps the result optimal while the number of steps - the length of the serial chain - drops by a
- *             quarter to a third on long searches.
- *   stop    : the open set is empty or its smallest f is not below G: FOUND if the goal has been closed (cost G), else
- *             NO_PATH | n_expanded == max_expansions (LIMIT, at once)
+ *   step    : let fmin be the smallest f in the open set.  Up to DMPP_JPS_BATCH (4) entries with
+ *             f = fmin are taken, the most recently pushed first; an entry whose cell is already closed
+ *             is dropped, the others are closed in that order (the k-th cell closed is expansion k) and
+ *             form the batch.  Then the batch nodes, in that order, push their successors (s = 0..7).
+ *             Every batch node has the minimal f, so its g is final: the search stays optimal while a
+ *             64-lane wave expands four nodes at once.
+ *   stop    : goal closed (FOUND, at once: the rest of the step is skipped) | open set empty (NO_PATH)
+ *             | n_expanded == max_expansions (LIMIT, at once)
  *             | more than open_cap = min(bucket_cap, DMPP_OPEN_CAP) live entries (OVERFLOW).
  *   path    : from the goal, each closed cell knows its arriving direction and run length; the cells
  *             of every run are written out, start..goal.
- *   n_rounds: number of steps.
+ *   n_rounds: number of pops whose f exceeds every f popped before (+1 for the first).
  */
 static const int DX[8] = { 1, 1, 0, -1, -1, -1, 0, 1 };
 static const int DY[8] = { 0, 1, 1, 1, 0, -1, -1, -1 };
@@ -197,33 +192,28 @@ void orc_grid_search(const PlannerConfig* c, const uint8_t* grid, int start_cell
 
     open[n_open++] = (OEnt){ hfun(start_cell % W, start_cell / W, gx, gy), start_cell, 8, 0 };
     out->n_pushed = 1;
-    int status = -1;
-    int Gbest = -1;                                    /* cost of the best closing of the goal so far */
-    int32_t* gclosed = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+    int status = -1, fmax = -1;
     while (status < 0) {
-        if (n_open == 0) { status = Gbest >= 0 ? DMPP_G_FOUND : DMPP_G_NO_PATH; break; }
+        if (n_open == 0) { status = DMPP_G_NO_PATH; break; }
         int fmin = open[0].f;
         for (int i = 1; i < n_open; i++) if (open[i].f < fmin) fmin = open[i].f;
-        if (Gbest >= 0 && fmin >= Gbest) { status = DMPP_G_FOUND; break; }           /* nothing left that could beat the goal's cost */
-        out->n_rounds++;
         OEnt batch[DMPP_JPS_BATCH]; int nb = 0;
         for (int t = 0; t < DMPP_JPS_BATCH && status < 0; t++) {
-            if (n_open == 0) break;
-            int bi = 0;                                /* the smallest f; among equals the latest push */
-            for (int i = 1; i < n_open; i++) if (open[i].f <= open[bi].f) bi = i;
+            int bi = -1;
+            for (int i = n_open - 1; i >= 0; i--) if (open[i].f == fmin) { bi = i; break; }    /* latest push first */
+            if (bi < 0) break;
             OEnt e = open[bi];
-            if (Gbest >= 0 && e.f >= Gbest) break;
             memmove(&open[bi], &open[bi + 1], sizeof(OEnt) * (size_t)(n_open - bi - 1));        /* keeps push order */
             n_open--;
-            const int ge = e.f - hfun(e.cell % W, e.cell / W, gx, gy);
-            if (closed[e.cell] && gclosed[e.cell] <= ge) continue;                /* already closed at least as cheaply */
-            closed[e.cell] = 1; gclosed[e.cell] = ge; pdir[e.cell] = (uint8_t)e.dir; prun[e.cell] = (uint16_t)e.run;
+            if (closed[e.cell]) continue;
+            closed[e.cell] = 1; pdir[e.cell] = (uint8_t)e.dir; prun[e.cell] = (uint16_t)e.run;
+            if (e.f > fmax) { fmax = e.f; out->n_rounds++; }
             int seq = out->n_expanded++;
             if (order && seq < order_cap) order[seq] = e.cell;
             out->order_digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)e.cell);
-            if (e.cell == goal_cell) { Gbest = ge; continue; }                         /* the goal is closed, never expanded */
             batch[nb++] = e;
-            if (out->n_expanded >= c->max_expansions) status = DMPP_G_LIMIT;
+            if (e.cell == goal_cell) { status = DMPP_G_FOUND; out->path_cost = e.f; }
+            else if (out->n_expanded >= c->max_expansions) status = DMPP_G_LIMIT;
         }
         if (status >= 0) break;
         for (int bn = 0; bn < nb && status < 0; bn++) {
@@ -253,7 +243,6 @@ void orc_grid_search(const PlannerConfig* c, const uint8_t* grid, int start_cell
                 if (!run) continue;
                 const int nx = x + run * DX[s], ny = y + run * DY[s];
                 const int fn = g + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
-                if (Gbest >= 0 && fn >= Gbest) continue;        /* cannot improve on the goal's cost */
                 if (n_open >= cap) { status = DMPP_G_OVERFLOW; break; }
                 open[n_open++] = (OEnt){ fn, ny * W + nx, s, run };
                 out->n_pushed++;
@@ -261,8 +250,6 @@ void orc_grid_search(const PlannerConfig* c, const uint8_t* grid, int start_cell
         }
     }
     out->status = status;
-    if (status == DMPP_G_FOUND) out->path_cost = Gbest;
-    free(gclosed);
     if (status == DMPP_G_FOUND) {
         int L = 1, cur = goal_cell;
         while (cur != start_cell) { L += prun[cur]; cur -= prun[cur] * (DY[pdir[cur]] * W + DX[pdir[cur]]); }

@@ -44,8 +44,12 @@ struct pp_planner {
     SceneState* d_state = nullptr; PlanOut* d_plan = nullptr; GridOut* d_gout[2] = { nullptr, nullptr };
     GlobalPoint2D* d_dec_ref = nullptr;
     // grid engine
-    uint8_t* d_grid = nullptr; uint16_t* d_pinfo = nullptr; uint32_t* d_closed = nullptr;
-    int32_t* d_order = nullptr; int32_t* d_path[2] = { nullptr, nullptr }; uint32_t* d_gbm[2] = { nullptr, nullptr }; int32_t* d_perm = nullptr; int32_t* d_cost = nullptr;
+    uint8_t* d_grid = nullptr; uint16_t* d_pinfo[2] = { nullptr, nullptr }; uint32_t* d_closed[2] = { nullptr, nullptr };
+    int32_t* d_order[2] = { nullptr, nullptr }; int32_t* d_path[2] = { nullptr, nullptr }; uint32_t* d_gbm[2] = { nullptr, nullptr };
+    int32_t* d_perm[2] = { nullptr, nullptr }; int32_t* d_cost[2] = { nullptr, nullptr };
+    // Long searches (many obstacles, large grids) overlap their tails: the searches of odd ticks run on a second stream, and
+    // every buffer a search touches exists per tick parity
+    hipStream_t stream_m2 = nullptr; int n_obs_total = 0;
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
     bool search_gbm = false; int search_lds = 0; int raster_band_rows = 0;
@@ -179,10 +183,12 @@ int setup_grid_launch(pp_planner* h)
     }
     if (sizeof(dmpp::ScoreShared<16>) > 48u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_score<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(dmpp::ScoreShared<16>));
-    if (!h->d_perm) { int r = dmalloc(&h->d_perm, (size_t)h->caps.max_scenes); if (r) return r; }
-    if (!h->d_cost) {
-        int r = dmalloc(&h->d_cost, (size_t)h->caps.max_scenes); if (r) return r;
-        HIP_TRY(hipMemsetAsync(h->d_cost, 0, (size_t)h->caps.max_scenes * sizeof(int32_t), h->stream));
+    for (int q = 0; q < 2; q++) {
+        if (!h->d_perm[q]) { int r = dmalloc(&h->d_perm[q], (size_t)h->caps.max_scenes); if (r) return r; }
+        if (!h->d_cost[q]) {
+            int r = dmalloc(&h->d_cost[q], (size_t)h->caps.max_scenes); if (r) return r;
+            HIP_TRY(hipMemsetAsync(h->d_cost[q], 0, (size_t)h->caps.max_scenes * sizeof(int32_t), h->stream));
+        }
     }
     for (int q = 0; q < 2; q++) if (!h->d_gbm[q]) {   // bit-packed occupancy, row- and column-major: written by k_rasterise, read by k_search
         int r = dmalloc(&h->d_gbm[q], (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
@@ -218,6 +224,7 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithPriority(&h->stream_m2, hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     // The two side streams (front, score) may use 88 % of the CUs; the rest run nothing but search waves.  The search
     // needs two 80 KB workgroups per CU and the hardware does not keep the short kernels' workgroups out of its way by
     // queue priority alone; measured on configs[1] (with the time-keyed launch order): 0.596 ms per tick without the
@@ -263,10 +270,12 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
         h->grid_cells = (size_t)cfg->grid_w * cfg->grid_h;
         h->bucket_cap0 = cfg->bucket_cap; h->max_path0 = cfg->max_path;
         if ((r = dmalloc(&h->d_grid, h->grid_cells))) return bail(r);             // one scene as bytes, filled on demand (pp_get_grid)
-        if ((r = dmalloc(&h->d_pinfo, ns * h->grid_cells))) return bail(r);
-        if ((r = dmalloc(&h->d_closed, ns * (h->grid_cells / 32)))) return bail(r);
+        for (int q = 0; q < 2; q++) {
+            if ((r = dmalloc(&h->d_pinfo[q], ns * h->grid_cells))) return bail(r);
+            if ((r = dmalloc(&h->d_closed[q], ns * (h->grid_cells / 32)))) return bail(r);
+        }
         for (int q = 0; q < 2; q++) if ((r = dmalloc(&h->d_path[q], ns * (size_t)cfg->max_path))) return bail(r);
-        if (caps->order_cap > 0 && (r = dmalloc(&h->d_order, ns * (size_t)caps->order_cap))) return bail(r);
+        for (int q = 0; q < 2; q++) if (caps->order_cap > 0 && (r = dmalloc(&h->d_order[q], ns * (size_t)caps->order_cap))) return bail(r);
         if ((r = setup_grid_launch(h))) return bail(r);
     }
     h->scratch_bytes = 4u << 20;
@@ -280,13 +289,14 @@ int pp_destroy(pp_handle h)
 {
     if (!h) return PP_OK;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipStream_t st : { h->stream, h->stream_m2, h->stream_r, h->stream_s }) if (st) (void)hipStreamSynchronize(st);
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     if (h->stream_s) (void)hipStreamSynchronize(h->stream_s);
     void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now[0], h->d_obs_now[1], h->d_state, h->d_plan,
-                     h->d_gout[0], h->d_gout[1], h->d_dec_ref, h->d_grid, h->d_pinfo, h->d_closed, h->d_order, h->d_path[0], h->d_path[1],
-                     h->d_gbm[0], h->d_gbm[1], h->d_perm, h->d_cost, h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad };
+                     h->d_gout[0], h->d_gout[1], h->d_dec_ref, h->d_grid, h->d_pinfo[0], h->d_pinfo[1], h->d_closed[0], h->d_closed[1],
+                     h->d_order[0], h->d_order[1], h->d_path[0], h->d_path[1], h->d_gbm[0], h->d_gbm[1], h->d_perm[0], h->d_perm[1],
+                     h->d_cost[0], h->d_cost[1], h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int q = 0; q < 2; q++) { if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]); if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]); }
     if (h->ev_raster) (void)hipEventDestroy(h->ev_raster);
@@ -294,6 +304,7 @@ int pp_destroy(pp_handle h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream_r) { (void)hipStreamSynchronize(h->stream_r); (void)hipStreamDestroy(h->stream_r); }
+    if (h->stream_m2) (void)hipStreamDestroy(h->stream_m2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PP_OK;
@@ -338,7 +349,7 @@ int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoin
         h->have_motion = true;
     }
     HIP_TRY(hipStreamSynchronize(h->stream));     // the caller may reuse its buffers
-    h->n_scenes = n_scenes;
+    h->n_scenes = n_scenes; h->n_obs_total = n_obs_total;
     return PP_OK;
 }
 
@@ -415,7 +426,7 @@ int pp_set_egos(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs
     int bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, h->d_map_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->n_scenes = n_scenes;
+    h->n_scenes = n_scenes; h->n_obs_total = n_obs_total;
     if (bad) return fail(PP_ERR_ARG, "pp_set_egos: " + std::to_string(bad) + " scene(s) name a road or lane outside the map");
     return PP_OK;
 }
@@ -465,12 +476,17 @@ int pp_plan_tick(pp_handle h)
     // microseconds; only Decision + Planning run beside the grid engine there).
     const int p = h->parity ^ 1;
     const bool piped = c.grid_stage && n >= kPipelineMinScenes;
-    hipStream_t sm = h->stream;                                        // search chain
+    // consecutive searches overlap when a search is long next to the front chain (Decision, Planning and the rasteriser share
+    // one stream and bound the tick from below): many obstacles per scene, or grids beyond 512 x 512.  Measured: 256 obstacles
+    // +40 %, 2048 x 2048 +7 %, but -8 % on 64 obstacles at 512 x 512, where the front chain is as long as the search.
+    const bool overlap = piped && ((long long)c.grid_w * c.grid_h > 512ll * 512ll || (long long)h->n_obs_total >= 128ll * n);
+    hipStream_t sm = (overlap && p) ? h->stream_m2 : h->stream;        // search chain
     hipStream_t sf = piped ? h->stream_r : h->stream;                  // front chain
     hipStream_t ss = piped ? h->stream_s : h->stream;                  // score chain
     hipStream_t sr = c.grid_stage ? h->stream_r : h->stream;           // Decision + Planning
     if (h->score_recorded[p]) { HIP_TRY(hipStreamWaitEvent(sf, h->ev_score[p], 0)); HIP_TRY(hipStreamWaitEvent(sm, h->ev_score[p], 0)); }
     if (h->search_recorded[p]) HIP_TRY(hipStreamWaitEvent(sf, h->ev_search[p], 0));
+    if (!overlap && h->search_recorded[p ^ 1]) HIP_TRY(hipStreamWaitEvent(sm, h->ev_search[p ^ 1], 0));   // one search at a time (also after a switch of mode)
     if (h->front_recorded && sf == h->stream && h->front_unjoined) HIP_TRY(hipStreamWaitEvent(sf, h->ev_join, 0));   // Planning(t-1) -> snapshot(t) when not on the same stream
     h->front_unjoined = false;
     ObPoint* obs_now = h->d_obs_now[p];
@@ -504,14 +520,15 @@ int pp_plan_tick(pp_handle h)
         {
             Timed t(h, PP_K_SEARCH, sm);
             // heaviest scenes first (by last tick's cost) - pointless while every scene is resident at once (2 waves per CU)
-            const int32_t* perm = n > kSearchSlots ? h->d_perm : nullptr;
-            if (perm) hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost, h->d_perm);
+            // keyed by the last search that is certainly complete: the previous tick's, or - when consecutive searches overlap - the one before
+            const int32_t* perm = n > kSearchSlots ? h->d_perm[p] : nullptr;
+            if (perm) hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[overlap ? p : p ^ 1], h->d_perm[p]);
             if (h->search_gbm)
                 hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap, perm, h->d_in,
-                                   h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost);
+                                   h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost[p]);
             else
                 hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap,
-                                   perm, h->d_in, h->d_closed, h->d_pinfo, h->d_order, h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost);
+                                   perm, h->d_in, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost[p]);
         }
         h->search_recorded[p] = piped;                   // (one-stream mode: stream order is enough, no events on the latency path)
         if (piped) { HIP_TRY(hipEventRecord(h->ev_search[p], sm)); HIP_TRY(hipStreamWaitEvent(ss, h->ev_search[p], 0)); }
@@ -583,10 +600,10 @@ int pp_get_grid(pp_handle h, int scene, uint8_t* grid)
 }
 int pp_get_order(pp_handle h, int scene, int32_t* order, int cap)
 {
-    if (!h || !order || !h->d_order) return fail(PP_ERR_STATE, "expansion order was not requested (caps.order_cap == 0)");
+    if (!h || !order || !h->d_order[0]) return fail(PP_ERR_STATE, "expansion order was not requested (caps.order_cap == 0)");
     if (scene < 0 || scene >= h->n_scenes) return fail(PP_ERR_ARG, "scene out of range");
     if (cap > h->caps.order_cap) cap = h->caps.order_cap;
-    return fetch(h, order, h->d_order + (size_t)scene * h->caps.order_cap, (size_t)cap * sizeof(int32_t));
+    return fetch(h, order, h->d_order[h->parity] + (size_t)scene * h->caps.order_cap, (size_t)cap * sizeof(int32_t));
 }
 int pp_get_refpath(pp_handle h, int scene, GlobalPoint2D* pts, int cap)
 {
@@ -863,7 +880,7 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes)
     case PP_BUF_GRID: p = h->d_gbm[h->parity]; b = ns * 2 * (h->grid_cells / 8); break;      // bit-packed: per scene row-major then column-major
     case PP_BUF_PATH: p = h->d_path[h->parity]; b = ns * (size_t)h->max_path0 * 4; break;
     case PP_BUF_LANE_ATTR: p = h->d_attr; b = (size_t)h->caps.max_lane_pts_total; break;
-    case PP_BUF_ORDER: p = h->d_order; b = ns * (size_t)h->caps.order_cap * 4; break;
+    case PP_BUF_ORDER: p = h->d_order[h->parity]; b = ns * (size_t)h->caps.order_cap * 4; break;
     default: break;
     }
     if (bytes) *bytes = b;

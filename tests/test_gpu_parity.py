@@ -446,7 +446,7 @@ def test_lanechange_needs_attributes(dm):
 
 
 # ---- ticks enqueued back to back (no host sync in between): the pipelined three-stream tick -----------------
-@pytest.mark.parametrize("n,grid,n_obs", [(320, 128, 24), (64, 128, 24), (300, 512, 64)])
+@pytest.mark.parametrize("n,grid,n_obs", [(320, 128, 24), (64, 128, 24), (300, 512, 64), (272, 128, 136)])   # the last: consecutive searches overlap
 def test_back_to_back_ticks_match_synchronised_ones(dm, oracle, n, grid, n_obs):
     """Dynamic obstacles, replanning every tick, 9 ticks without a host sync: the front of tick t+1 and the scoring of
     tick t overlap the search (double-buffered by tick parity).  The final state, plan and grid results must be those

@@ -49,7 +49,7 @@ struct pp_planner {
     int32_t* d_perm[2] = { nullptr, nullptr }; int32_t* d_cost[2] = { nullptr, nullptr };
     // Long searches (many obstacles, large grids) overlap their tails: the searches of odd ticks run on a second stream, and
     // every buffer a search touches exists per tick parity
-    hipStream_t stream_m2 = nullptr; int n_obs_total = 0;
+    hipStream_t stream_m2 = nullptr; int n_obs_total = 0; int overlap_override = -1;
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
     bool search_gbm = false; int search_lds = 0; int raster_band_rows = 0;
@@ -241,6 +241,7 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     const uint32_t cu_words = (uint32_t)((side_cus + 31) / 32);
     if (side_cus > 0 && hipExtStreamCreateWithCUMask(&h->stream_r, cu_words, cu_mask) != hipSuccess) { (void)hipGetLastError(); h->stream_r = nullptr; side_cus = 0; }
     if (side_cus > 0 && hipExtStreamCreateWithCUMask(&h->stream_s, cu_words, cu_mask) != hipSuccess) { (void)hipGetLastError(); h->stream_s = nullptr; }
+    if (const char* e = std::getenv("DMPP_OVERLAP")) h->overlap_override = std::atoi(e);
     if (!h->stream_r)
     if (hipStreamCreateWithPriority(&h->stream_r, hipStreamNonBlocking, prio_least) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     if (!h->stream_s)
@@ -479,7 +480,8 @@ int pp_plan_tick(pp_handle h)
     // consecutive searches overlap when a search is long next to the front chain (Decision, Planning and the rasteriser share
     // one stream and bound the tick from below): many obstacles per scene, or grids beyond 512 x 512.  Measured: 256 obstacles
     // +40 %, 2048 x 2048 +7 %, but -8 % on 64 obstacles at 512 x 512, where the front chain is as long as the search.
-    const bool overlap = piped && ((long long)c.grid_w * c.grid_h > 512ll * 512ll || (long long)h->n_obs_total >= 128ll * n);
+    bool overlap = piped && ((long long)c.grid_w * c.grid_h > 512ll * 512ll || (long long)h->n_obs_total >= 128ll * n);
+    if (h->overlap_override >= 0) overlap = piped && h->overlap_override != 0;      // env DMPP_OVERLAP (measurement knob)
     hipStream_t sm = (overlap && p) ? h->stream_m2 : h->stream;        // search chain
     hipStream_t sf = piped ? h->stream_r : h->stream;                  // front chain
     hipStream_t ss = piped ? h->stream_s : h->stream;                  // score chain

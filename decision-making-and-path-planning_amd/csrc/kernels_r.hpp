@@ -120,7 +120,8 @@ struct DecShared {
                   RF[DMPP_FRONT_POINTS], RR[DMPP_REAR_POINTS];
     GlobalPoint2D tmp[4][DMPP_FRONT_POINTS];      // one offset candidate per wave
     GlobalPoint2D ref[DMPP_MAX_REFPATH];          // junction front path
-    double s[4][DMPP_MAX_REFPATH];                // arc-length scratch per wave
+    double s0[DMPP_MAX_REFPATH];                  // arc-length scratch of wave 0 (also the junction path, up to 512 points)
+    double s123[3][DMPP_FRONT_POINTS];            // ... of waves 1..3 (corridors and sweep candidates: <= 120 points)
     ObPoint obs[kMaxObsLds];
     SoResult around[6];
     double sweep_lng[2 * DMPP_MAX_SWEEP];
@@ -396,7 +397,7 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         const double LO[6] = { -hv, -hv, -hv, -hv, -0.5 * W, -0.5 * W };
         const double HI[6] = { hv, hv, 0.5 * W, 0.5 * W, hv, hv };
         for (int t = wave; t < 6; t += 4) {
-            SoResult r = wave_search_obstacle(c, P[t], N[t], sh.s[wave], obs, m, LO[t], HI[t], lane);
+            SoResult r = wave_search_obstacle(c, P[t], N[t], wave == 0 ? sh.s0 : sh.s123[wave - 1], obs, m, LO[t], HI[t], lane);
             if (lane == 0) { sh.around[t] = r; sh.n[t] = N[t]; }
         }
         __syncthreads();
@@ -415,7 +416,7 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
                 const double off = (side == 0 ? -0.3 : 0.3) * (double)i;      // Decision.cpp:942,961
                 for (int k = lane; k < nF; k += DMPP_WAVE) sh.tmp[wave][k] = offset_point(c, sh.F, nF, k, off);
                 wave_sync();
-                SoResult r = wave_search_obstacle(c, sh.tmp[wave], nF, sh.s[wave], obs, m, -hv, hv, lane);
+                SoResult r = wave_search_obstacle(c, sh.tmp[wave], nF, wave == 0 ? sh.s0 : sh.s123[wave - 1], obs, m, -hv, hv, lane);
                 if (lane == 0) sh.sweep_lng[side * DMPP_MAX_SWEEP + i] = r.dis_lng;
                 wave_sync();
             }
@@ -570,7 +571,7 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         }
         __syncthreads();
         if (wave == 0) {
-            SoResult r = wave_search_obstacle(c, sh.ref, n, sh.s[0], obs, m, -hv, hv, lane);
+            SoResult r = wave_search_obstacle(c, sh.ref, n, sh.s0, obs, m, -hv, hv, lane);
             if (lane == 0) sh.around[0] = r;
         }
         __syncthreads();

@@ -287,8 +287,8 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     __shared__ uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24
     __shared__ uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
     __shared__ uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
-    __shared__ int dc_owner[kMaxDiag], dc_run[kMaxDiag];                      // the diagonal jumps of the current step
-    __shared__ uint32_t sj_job[kDiagGroup]; __shared__ int sj_run[kDiagGroup]; // its straight jumps (<= 8)
+    __shared__ int dc_owner[kMaxDiag];                                         // the (node, s) lanes of the diagonal jumps of the current step
+    __shared__ uint32_t sj_job[kDiagGroup];                                    // its straight jumps (<= 8), packed
     __shared__ uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
     __shared__ uint16_t c_info[kClosedTab];    // arriving direction | run length << 4 of the cell in the same slot
     if ((int)blockIdx.x >= n_scenes) return;
@@ -590,7 +590,6 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
 #else
                 const int r = jump_lane(V, last ? sact : dact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx);
 #endif
-                if (sact) sj_run[sji] = r;
                 bool cblk = false, cstop = false;
                 if (dact && (t & 1) == 0) {
                     cblk = B.blk(cx, cy);
@@ -602,11 +601,12 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
                 const unsigned gb = (unsigned)(bk >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
                 int drun = kDiagK;
                 if (gs) { const int k1 = (__ffs((int)gs) - 1) >> 1; drun = ((gb >> (2 * k1)) & 1u) ? 0 : k1 + 1; }
-                if (dact && t == 0) dc_run[dci] = drun;
-                wave_order();
+                // results back to the owner lanes: a straight one sits on lane 14 | 15 of group my_sj / 2, a diagonal one on its whole group
+                const int from_s = __shfl(r, ((my_sj >> 1) & (kDiagPerRound - 1)) * kDiagGroup + (kDiagGroup - 2) + (my_sj & 1), 64);
+                const int from_d = __shfl(drun, (my_dc & (kDiagPerRound - 1)) * kDiagGroup, 64);
+                if (rnd == 0 && want_jump) run = from_s;
+                if (want_diag && (my_dc / kDiagPerRound) == rnd) run = from_d;
             }
-            if (want_jump) run = sj_run[my_sj];
-            if (want_diag) run = dc_run[my_dc];
 #ifdef DMPP_DEBUG_SEARCH
             long long te2 = clock64(); t_jump += te2 - td; c_jobs += n_dc; c_pass += n_rounds_j;
 #endif

@@ -568,3 +568,42 @@ def test_non_square_grids(dm, oracle, gw, gh):
         assert np.array_equal(pl.get_grid(s_), r[6][s_])
     found = int((res[-1][5]["status"] == dm.G_FOUND).sum())
     assert found >= (4 if gw > 32 else 0)
+
+
+# ---- the bench workloads at their full size (BASELINE configs[1], [3], [4]) -----------------------------
+@pytest.mark.parametrize("grid,n_obs,dynamic,n_ticks", [(512, 64, 0, 4), (512, 256, 1, 30), (2048, 64, 0, 2)],
+                         ids=["configs1", "configs3", "configs4"])
+def test_bench_workloads_full_size(dm, oracle, grid, n_obs, dynamic, n_ticks):
+    """Exactly what bench.py times — 1024 scenes of seed 0, ticks queued back to back without a host sync —
+    against the oracle ticking the same scenes: every PlanOut / SceneState / GridOut field (the digest in GridOut
+    covers the expansion order and the path cells), plus the full order and path of a sample of scenes."""
+    import os
+    cfg = dm.default_config(grid)
+    if dynamic:
+        cfg["dynamic_obstacles"] = 1
+        cfg["force_replan"] = 1
+    n = 1024
+    sc = dm.gen_scenes(cfg, 0, n, n_obs, junction_every=8)
+    cap = grid * grid if grid <= 512 and not dynamic else 0
+    pl = dm.Planner(cfg, device=0, max_scenes=n, max_obs_total=n * n_obs, order_cap=cap)
+    pl.set_scenes(sc)
+    pl.set_state(sc["state"])
+    for _ in range(n_ticks):
+        pl.tick(sync=False)
+    pl.sync()
+    plan_g, st_g, gout_g = pl.get_plan(), pl.get_state(), pl.get_grid_out()
+    st_o = sc["state"].copy()
+    threads = min(64, os.cpu_count() or 8)
+    for _ in range(n_ticks):
+        plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st_o, n_threads=threads, want_grid=True)
+    _assert_tick((plan_g, st_g, gout_g, plan_o, st_o, gout_o, None), f"{grid}/{n_obs}/{n_ticks} ticks")
+    print("status histogram:", np.bincount(gout_o["status"], minlength=5).tolist(),
+          "max expanded:", int(gout_o["n_expanded"].max()))
+    if cap and not dynamic:
+        for s in (0, 406, 1023):                          # 406: the slowest search of the batch
+            st1 = sc["state"].copy()
+            for _ in range(n_ticks):
+                _, go, grid_o, order_o, path_o = oracle.plan_tick_one(cfg, sc, s, st1, order_cap=cap)
+            assert (pl.get_grid(s) == grid_o).all(), s
+            assert (pl.get_order(s, int(go["n_expanded"])) == order_o).all(), s
+            assert (pl.get_path(s, int(go["path_len"])) == path_o).all(), s

@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--latency-ticks", type=int, default=200)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 path with ranks sharing the GPUs of a smaller box (never a measured number)")
     return ap.parse_args()
 
 
@@ -67,12 +69,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the planning path has no CPU fallback")
+    # --backend gloo is a rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (the ranks share the
+    # cards, the scatter / gather go through host tensors); the measured runs use RCCL, one rank per GPU
+    rehearsal = args.backend != "nccl"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
+    comm_dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group(args.backend)
+        else:
+            dist.init_process_group("nccl", device_id=comm_dev)   # nccl == RCCL on ROCm
 
     cfg = dm.default_config(args.grid)
     if args.dynamic:
@@ -89,7 +100,8 @@ def main():
         pl.set_state(sc["state"])
     else:
         from dmpp_amd_pkg import sharding
-        recv = sharding.scatter_scenes(dm, dist, torch, cfg, n, n_obs, rank, world, torch.device('cuda', local_rank))
+        recv = sharding.scatter_scenes(dm, dist, torch, cfg, n, n_obs, rank, world, comm_dev)
+        recv = {k: v.cuda() for k, v in recv.items()}
         torch.cuda.synchronize()
         lib = pl.lib
         dm._check(lib.pp_set_scenes(pl.h, n, recv["scene_in"].data_ptr(), recv["lane_pool"].data_ptr(), recv["attr_pool"].data_ptr(),
@@ -119,7 +131,7 @@ def main():
     kms = pl.kernel_ms()
     pl.set_profile(False)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -127,7 +139,7 @@ def main():
     gout = pl.get_grid_out()
     if dist is not None:
         from dmpp_amd_pkg import sharding
-        mine = torch.from_numpy(gout["order_digest"].astype(np.int64)).cuda()
+        mine = torch.from_numpy(gout["order_digest"].astype(np.int64)).to(comm_dev)
         allg = sharding.gather_results(dist, torch, mine, rank, world)
         torch.cuda.synchronize()
         if rank == 0:
@@ -203,7 +215,8 @@ def main():
                                    % (3 if args.dynamic else (2 if world > 1 else 1), n, args.grid, args.grid, n_obs,
                                       "dynamic" if args.dynamic else "static"),
                        "scenes_per_gpu": n, "global_scenes": n * world, "grid": args.grid, "obstacles": n_obs,
-                       "parallelism": "scene-sharded x%d, RCCL scatter/gather outside the timed region" % world,
+                       "parallelism": ("scene-sharded x%d, RCCL scatter/gather outside the timed region" % world)
+                                      + (" [REHEARSAL: gloo, ranks share GPUs - not a measurement]" if rehearsal else ""),
                        "algorithmic_bytes_per_tick": b_r + b_g,
                        "tick_GBps": (b_r + b_g) * n * world * args.steps / dt / 1e9},
             "p50_plan_latency_ms_batch1": p50_ms,

@@ -607,3 +607,28 @@ def test_bench_workloads_full_size(dm, oracle, grid, n_obs, dynamic, n_ticks):
             assert (pl.get_grid(s) == grid_o).all(), s
             assert (pl.get_order(s, int(go["n_expanded"])) == order_o).all(), s
             assert (pl.get_path(s, int(go["path_len"])) == path_o).all(), s
+
+
+def test_bench_two_ranks_rehearsal(dm, oracle):
+    """bench.py's N > 1 code path (scatter from rank 0, device pointers into pp_set_scenes, max-over-ranks timing,
+    gather) with two ranks sharing this box's GPU over gloo; the measured runs use RCCL with one rank per GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--scenes", "96", "--grid", "128", "--obstacles", "16", "--backend", "gloo", "--no-cpu-baseline", "--latency-ticks", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    print(r.stdout[-2000:], r.stderr[-1500:])
+    assert r.returncode == 0
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_scenes"] == 192 and line["value"] > 0
+    cfg = dm.default_config(128)                          # rank 0's shard is seeds 0..95: same statuses as the oracle's
+    sc = dm.gen_scenes(cfg, 0, 96, 16, junction_every=8)
+    st = sc["state"].copy()
+    for _ in range(4):
+        _, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st, n_threads=8, want_grid=True)
+    assert line["search_status_counts"] == np.bincount(gout_o["status"], minlength=6).tolist()

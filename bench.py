@@ -145,6 +145,28 @@ def main():
         if rank == 0:
             assert len(allg) == world and all(t.numel() == n for t in allg)
 
+    # ---- Part R alone (Decision + Planning ticks, grid engine off) on the same scenes, rank 0; SURVEY 8(d) asks for
+    #      the two parts separately as well as combined.  Part G's kernels never run without Part R's inputs, so its
+    #      figure is the serial sum of its kernels' average launch times from the timed region above. ----
+    parts = None
+    if rank == 0:
+        cfg_r = cfg.copy()
+        cfg_r["grid_stage"] = 0
+        pl.set_config(cfg_r)
+        for _ in range(max(args.warmup, 2)):
+            pl.tick()
+        pl.sync()
+        r0 = time.perf_counter()
+        for _ in range(args.steps):
+            pl.tick()
+        pl.sync()
+        r_dt = time.perf_counter() - r0
+        pl.set_config(cfg)
+        g_ms = sum(v[0] / max(v[1], 1) for k, v in kms.items() if k in ("k_effective_obstacles", "k_rasterise", "k_order", "k_search", "k_score"))
+        parts = {"R_only_ticks_per_s": n * args.steps / r_dt, "R_only_ms_per_step": r_dt / args.steps * 1e3,
+                 "G_kernels_serial_ms": g_ms, "G_kernels_serial_ticks_per_s": (n / (g_ms * 1e-3)) if g_ms > 0 else None,
+                 "note": "per GPU; R = k_decision + k_planning with the grid stage off; G = sum of the grid-engine kernels' average launch times inside the combined tick"}
+
     # ---- p50 plan latency, batch = 1 (rank 0) ----
     p50_ms = None
     if rank == 0 and args.latency_ticks > 0:
@@ -168,19 +190,43 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding
         orc = oracle_binding.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
-        cores = os.cpu_count() or 1
-        ns = min(n, 256)
-        scc = dm.gen_scenes(cfg, 0, ns, n_obs, junction_every=8)
+        ncpu = os.cpu_count() or 1
+        quota = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else float(q) / float(per)
+        except (OSError, ValueError):
+            pass
+        scc = dm.gen_scenes(cfg, 0, n, n_obs, junction_every=8)       # the GPU's own batch
         stc = scc["state"].copy()
-        orc.plan_tick_batch(cfg, scc, stc, n_threads=cores)          # warm-up tick
-        ticks, c0 = 0, time.perf_counter()
-        while time.perf_counter() - c0 < args.cpu_seconds:
-            orc.plan_tick_batch(cfg, scc, stc, n_threads=cores)
-            ticks += 1
+        orc.plan_tick_batch(cfg, scc, stc, n_threads=min(ncpu, 16))  # warm-up tick
+        # A GPU box may grant this job fewer CPUs than it shows (a cgroup quota): more threads than that only get
+        # throttled.  Time a few ticks at several thread counts and keep the fastest; `cores` reports that count.
+        cores, per_tick = 1, None
+        for cand in sorted({min(ncpu, k) for k in (8, 16, 32, 64, 128, ncpu)}):
+            c0 = time.perf_counter()
+            orc.plan_tick_batch(cfg, scc, stc, n_threads=cand, n_ticks=4)
+            t = (time.perf_counter() - c0) / 4
+            if per_tick is None or t < per_tick:
+                cores, per_tick = cand, t
+        # every thread takes its block of scenes through all the ticks on its own (scenes are independent): no barrier
+        # between ticks and the thread start-up is paid once - the CPU's best case for this workload
+        ticks = int(min(max(args.cpu_seconds / per_tick, 1), 40000))
+        c0 = time.perf_counter()
+        orc.plan_tick_batch(cfg, scc, stc, n_threads=cores, n_ticks=ticks)
         cdt = time.perf_counter() - c0
-        cpu = {"value": ns * ticks / cdt, "unit": "ticks/s", "cores": cores, "kind": "port",
-               "sample": f"{ticks} ticks x {ns} scenes of the same workload ({args.grid}x{args.grid}, {n_obs} obstacles), "
-                         f"oracle C port on {cores} pthreads, {cdt:.1f} s"}
+        ns1 = min(n, 64)
+        sc1t = dm.gen_scenes(cfg, 0, ns1, n_obs, junction_every=8)
+        st1 = sc1t["state"].copy()
+        orc.plan_tick_batch(cfg, sc1t, st1, n_threads=1)
+        one0 = time.perf_counter()
+        one_ticks = 20
+        orc.plan_tick_batch(cfg, sc1t, st1, n_threads=1, n_ticks=one_ticks)
+        one_dt = time.perf_counter() - one0
+        cpu = {"value": n * ticks / cdt, "unit": "ticks/s", "cores": cores, "kind": "port",
+               "single_thread_ticks_per_s": ns1 * one_ticks / one_dt, "cpu_count": ncpu, "cgroup_cpu_quota": quota,
+               "sample": f"{ticks} consecutive ticks x {n} scenes of the same workload ({args.grid}x{args.grid}, {n_obs} obstacles), "
+                         f"oracle C port, {cores} pthreads (fastest of 8..{ncpu} on this box: os.cpu_count() = {ncpu}, cgroup CPU quota = {quota}) each ticking its own block of scenes, {cdt:.1f} s"}
 
     if rank == 0:
         b_r, b_g, per_kernel = algorithmic_bytes(cfg, n_obs)
@@ -220,6 +266,7 @@ def main():
                        "algorithmic_bytes_per_tick": b_r + b_g,
                        "tick_GBps": (b_r + b_g) * n * world * args.steps / dt / 1e9},
             "p50_plan_latency_ms_batch1": p50_ms,
+            "parts": parts,
             "search_status_counts": np.bincount(gout["status"], minlength=6).tolist(),
             "kernel_ms_avg": {k: (v[0] / max(v[1], 1)) for k, v in kms.items()},
             # algorithmic bytes of each kernel over its own average launch time; the kernels of neighbouring

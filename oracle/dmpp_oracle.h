@@ -67,6 +67,10 @@ void orc_plan_tick(const PlannerConfig*, const SceneIn*, const GlobalPoint3D* la
 void orc_plan_tick_batch(const PlannerConfig*, int n, const SceneIn*, const GlobalPoint3D* lane_pool,
                          const uint8_t* lane_attr_pool, const GlobalPoint2D* ref_pool, const ObPoint* obs_pool, const ObMotion* mot_pool,
                          SceneState*, PlanOut*, GridOut*, uint8_t* grids, int n_threads);
+/* the same for n_ticks consecutive ticks: every thread runs its scenes through all of them (outputs of the last tick) */
+void orc_plan_ticks_batch(const PlannerConfig*, int n, const SceneIn*, const GlobalPoint3D* lane_pool,
+                          const uint8_t* lane_attr_pool, const GlobalPoint2D* ref_pool, const ObPoint* obs_pool, const ObMotion* mot_pool,
+                          SceneState*, PlanOut*, GridOut*, uint8_t* grids, int n_threads, int n_ticks);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ class Oracle:
         L.orc_effective_obstacles.argtypes = [vp, vp, vp, ci, ci, vp]
         L.orc_plan_tick.argtypes = [vp] * 10 + [vp, vp, ci, vp, ci]
         L.orc_plan_tick_batch.argtypes = [vp, ci] + [vp] * 10 + [ci]
+        L.orc_plan_ticks_batch.argtypes = [vp, ci] + [vp] * 10 + [ci, ci]
 
     # ---- scalar helpers ----
     def GetLatDis(self, cfg, cur, pt, nxt):
@@ -130,16 +131,16 @@ class Oracle:
         return out
 
     # ---- whole tick ----
-    def plan_tick_batch(self, cfg, sc, state, n_threads=1, want_grid=True, keep_grids=False):
-        """Runs one oracle tick over all scenes; updates `state` in place."""
+    def plan_tick_batch(self, cfg, sc, state, n_threads=1, want_grid=True, keep_grids=False, n_ticks=1):
+        """Runs n_ticks oracle ticks over all scenes (outputs of the last one); updates `state` in place."""
         n = len(sc["scene_in"])
         plan = np.zeros(n, dm.PlanOut)
         gout = np.zeros(n, dm.GridOut) if want_grid else None
         grids = None
         if keep_grids:
             grids = np.zeros((n, int(cfg["grid_h"][0]), int(cfg["grid_w"][0])), np.uint8)
-        self.L.orc_plan_tick_batch(_p(cfg), n, _p(sc["scene_in"]), _p(sc["lane_pool"]), _p(sc.get("attr_pool")), _p(sc["ref_pool"]),
-                                   _p(sc["obs_pool"]), _p(sc["mot_pool"]), _p(state), _p(plan), _p(gout), _p(grids), n_threads)
+        self.L.orc_plan_ticks_batch(_p(cfg), n, _p(sc["scene_in"]), _p(sc["lane_pool"]), _p(sc.get("attr_pool")), _p(sc["ref_pool"]),
+                                    _p(sc["obs_pool"]), _p(sc["mot_pool"]), _p(state), _p(plan), _p(gout), _p(grids), n_threads, n_ticks)
         return plan, gout, grids
 
     def plan_tick_one(self, cfg, sc, s, state, order_cap=0):

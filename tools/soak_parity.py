@@ -1,0 +1,77 @@
+"""Randomised soak of the HIP path against the CPU oracle (test infrastructure): many seeds, grid sizes,
+obstacle counts, static / dynamic obstacles, moving egos, several ticks per batch.  Every PlanOut / SceneState /
+GridOut field is compared exactly as the GPU tests do.  Usage (GPU box): python tools/soak_parity.py [seconds] [seed0]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch                                   # noqa: F401  (initialises the ROCm runtime the way bench.py does)
+torch.cuda.is_available()
+import dmpp_amd as dm
+import oracle_binding
+from parity_util import compare, move_ego
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    orc = oracle_binding.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+    rng = np.random.default_rng(seed0)
+    t0, it, scenes_done, bad_total = time.time(), 0, 0, 0
+    threads = 32
+    while time.time() - t0 < budget:
+        grid = int(rng.choice([64, 128, 256, 512, 512, 1024]))
+        n = int(rng.choice([1, 3, 17, 64, 200, 256, 300, 700])) if grid <= 512 else int(rng.choice([2, 9, 40]))
+        n_obs = int(rng.choice([0, 1, 8, 24, 64, 64, 130, 256, 520]))
+        if n * n_obs > 120000:
+            n_obs = 64
+        dynamic = int(rng.integers(0, 2))
+        first = int(rng.integers(0, 1 << 20))
+        jevery = int(rng.choice([0, 3, 8]))
+        n_ticks = int(rng.integers(1, 6))
+        cfg = dm.default_config(grid)
+        cfg["dynamic_obstacles"] = dynamic
+        cfg["force_replan"] = int(rng.integers(0, 2))
+        cfg["decision_stage"] = int(rng.integers(0, 4) != 0)
+        cfg["lanechg_stage"] = int(rng.integers(0, 4) != 0)
+        sync_each = bool(rng.integers(0, 2))
+        sc = dm.gen_scenes(cfg, first, n, n_obs, junction_every=jevery)
+        if rng.integers(0, 3) == 0:
+            sc["scene_in"]["period_last"] = float(rng.choice([100.0, 900.0, 1700.0]))
+        pl = dm.Planner(cfg, device=0, max_scenes=n, max_obs_total=max(n * n_obs, 1))
+        pl.set_state(sc["state"])
+        st_o = sc["state"].copy()
+        bad = []
+        for t in range(n_ticks):
+            if t and rng.integers(0, 2):
+                move_ego(sc, int(rng.integers(1, 9)), dlat=float(rng.choice([0.0, 0.2, -0.4])))
+            pl.set_scenes(sc)
+            pl.tick(sync=sync_each)
+            plan_o, gout_o, _ = orc.plan_tick_batch(cfg, sc, st_o, n_threads=threads, want_grid=True)
+            if sync_each or t == n_ticks - 1:
+                pl.sync()
+                plan_g, st_g, gout_g = pl.get_plan(), pl.get_state(), pl.get_grid_out()
+                bad += compare(plan_g, plan_o, "plan") + compare(st_g, st_o, "state")
+                bad += compare(gout_g["status"], gout_o["status"], "grid.status")
+                keep = gout_o["status"] != 3
+                bad += compare(gout_g[keep], gout_o[keep], "grid")
+        pl.close()
+        it += 1
+        scenes_done += n * n_ticks
+        tag = f"it {it} grid {grid} n {n} obs {n_obs} dyn {dynamic} first {first} jevery {jevery} ticks {n_ticks} sync {int(sync_each)} " \
+              f"dec {int(cfg['decision_stage'][0])} lc {int(cfg['lanechg_stage'][0])} force {int(cfg['force_replan'][0])}"
+        if bad:
+            bad_total += 1
+            print("MISMATCH", tag, bad[:6], flush=True)
+        elif it % 10 == 0:
+            print(f"ok {tag}  [{scenes_done} scene-ticks, {time.time() - t0:.0f} s]", flush=True)
+    print(f"SOAK DONE iterations {it} scene-ticks {scenes_done} mismatching batches {bad_total}", flush=True)
+    sys.exit(1 if bad_total else 0)
+
+
+if __name__ == "__main__":
+    main()

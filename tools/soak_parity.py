@@ -24,8 +24,13 @@ def main():
     t0, it, scenes_done, bad_total = time.time(), 0, 0, 0
     threads = 32
     while time.time() - t0 < budget:
-        grid = int(rng.choice([64, 128, 256, 512, 512, 1024]))
-        n = int(rng.choice([1, 3, 17, 64, 200, 256, 300, 700])) if grid <= 512 else int(rng.choice([2, 9, 40]))
+        grid = int(rng.choice([64, 128, 256, 512, 512, 1024, 2048] if seed0 % 2 == 0 else [64, 128, 256, 512, 512, 1024]))
+        if grid <= 512:
+            n = int(rng.choice([1, 3, 17, 64, 200, 256, 300, 700]))
+        elif grid == 1024:
+            n = int(rng.choice([2, 9, 40, 260]))          # 260: consecutive searches on two streams
+        else:
+            n = int(rng.choice([2, 5]))
         n_obs = int(rng.choice([0, 1, 8, 24, 64, 64, 130, 256, 520]))
         if n * n_obs > 120000:
             n_obs = 64

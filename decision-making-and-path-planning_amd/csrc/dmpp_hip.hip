@@ -52,7 +52,7 @@ struct pp_planner {
     hipStream_t stream_m2 = nullptr; int n_obs_total = 0; int overlap_override = -1;
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
-    bool search_gbm = false; int search_lds = 0; int raster_band_rows = 0;
+    bool search_gbm = false; int search_lds = 0; int raster_band_rows = 0; bool raster_band_fixed = false;
     hipStream_t stream_r = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the R kernels run beside the grid engine
     // k_score of tick t runs on its own stream beside the rasterise / search of tick t+1: the obstacle snapshot, the path
     // cells and GridOut are double-buffered by tick parity; ev_score[p] = the last k_score that used the buffers p
@@ -148,7 +148,7 @@ int setup_grid_launch(pp_planner* h)
     // rasterise: bands of 128 whole rows (measured best at 512 and at 2048 columns: 16-byte pieces of the column-major
     // bitmap per column and band, 4 - 16 bands per scene), both orientations of a band in LDS (32 bytes per column)
     int band = 128;
-    if (const char* e = std::getenv("DMPP_RASTER_BAND_ROWS")) band = std::atoi(e) / 32 * 32;       // tuning knob
+    if (const char* e = std::getenv("DMPP_RASTER_BAND_ROWS")) { band = std::atoi(e) / 32 * 32; h->raster_band_fixed = true; }   // tuning knob
     if (band < 32) band = 32; if (band > c.grid_h) band = c.grid_h;
     h->raster_band_rows = band;
     {   // both LDS bit bands of k_rasterise (row- and column-major) + its 10 KB of static tables
@@ -500,9 +500,14 @@ int pp_plan_tick(pp_handle h)
     if (sr != sf) { HIP_TRY(hipEventRecord(h->ev_fork, sf)); HIP_TRY(hipStreamWaitEvent(sr, h->ev_fork, 0)); }   // small batches: Decision + Planning beside the grid engine
     if (c.grid_stage) {
         Timed t(h, PP_K_RASTERISE, sf);
-        const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
-        const size_t lds = 2 * ((size_t)h->raster_band_rows * c.grid_w / 8);      // the band row-major and column-major
-        hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, sf, c, n, h->raster_band_rows,
+        // a handful of scenes does not fill the chip with 128-row bands: halve the bands (down to 32 rows) until there are
+        // some 512 workgroups - one scene at 512 x 512: 16 us -> 10 us of the latency-bound tick
+        int band_rows = h->raster_band_rows;
+        if (!h->raster_band_fixed)
+            while (band_rows > 32 && (long long)n * ((c.grid_h + band_rows - 1) / band_rows) < 512) band_rows /= 2;
+        const int bands = (c.grid_h + band_rows - 1) / band_rows;
+        const size_t lds = 2 * ((size_t)band_rows * c.grid_w / 8);                // the band row-major and column-major
+        hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, sf, c, n, band_rows,
                            h->d_in, obs_now, h->d_gbm[p]);
     }
     if (sf != sm) HIP_TRY(hipEventRecord(h->ev_raster, sf));

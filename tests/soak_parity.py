@@ -1,6 +1,6 @@
 """Randomised soak of the HIP path against the CPU oracle (test infrastructure): many seeds, grid sizes,
 obstacle counts, static / dynamic obstacles, moving egos, several ticks per batch.  Every PlanOut / SceneState /
-GridOut field is compared exactly as the GPU tests do.  Usage (GPU box): python tools/soak_parity.py [seconds] [seed0]"""
+GridOut field is compared exactly as the GPU tests do.  Usage (GPU box): python tests/soak_parity.py [seconds] [seed0].  Lives under tests/ because it loads the oracle."""
 import os
 import sys
 import time

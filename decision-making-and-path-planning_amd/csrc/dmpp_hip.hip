@@ -531,10 +531,10 @@ int pp_plan_tick(pp_handle h)
             const int32_t* perm = n > kSearchSlots ? h->d_perm[p] : nullptr;
             if (perm) hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[overlap ? p : p ^ 1], h->d_perm[p]);
             if (h->search_gbm)
-                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap, perm, h->d_in,
+                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(dmpp::kSearchBlock), (size_t)h->search_lds, sm, c, n, h->caps.order_cap, perm, h->d_in,
                                    h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost[p]);
             else
-                hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(DMPP_WAVE), (size_t)h->search_lds, sm, c, n, h->caps.order_cap,
+                hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(dmpp::kSearchBlock), (size_t)h->search_lds, sm, c, n, h->caps.order_cap,
                                    perm, h->d_in, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost[p]);
         }
         h->search_recorded[p] = piped;                   // (one-stream mode: stream order is enough, no events on the latency path)

@@ -277,8 +277,11 @@ k_order(int n_scenes, const int32_t* __restrict__ cost, int32_t* __restrict__ pe
         perm[atomicAdd(&base[kOrderClasses - 1 - min(max(cost[s], 0), kOrderClasses - 1)], 1)] = s;
 }
 
+// Four waves set a scene up (bitmaps into LDS, word summaries, empty closed set); then waves 1..3 leave and wave 0
+// searches alone - the search itself is one serial chain of steps.
+constexpr int kSearchSetupWaves = 4, kSearchBlock = kSearchSetupWaves * DMPP_WAVE;
 template <bool GBM>
-__global__ void __launch_bounds__(DMPP_WAVE)
+__global__ void __launch_bounds__(kSearchBlock)
 k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
          uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
          int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out)
@@ -299,7 +302,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     const long long t_entry = clock64(); long long t_loop = t_entry;
     const long long w_entry = wall_clock64();          // 100 MHz, the same counter on every CU: launch timeline of the scenes
 #endif
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (DMPP_WAVE - 1), wv = tid >> 6;
     const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5;
     const int HW = H >> 5;
     // dynamic LDS: the word summaries of both views (one bit per bitmap word), then - when they fit - the bitmaps
@@ -315,7 +318,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     {   // this scene's closed bit set starts empty (16 bytes per lane; done with before the first atomicOr, see the wait below)
         uint4* c4 = reinterpret_cast<uint4*>(closed);
         const uint4 z = { 0u, 0u, 0u, 0u };
-        for (int i = lane; i < (N >> 7); i += DMPP_WAVE) c4[i] = z;
+        for (int i = tid; i < (N >> 7); i += kSearchBlock) c4[i] = z;
     }
     uint16_t* pin = pinfo + (size_t)scene * N;
     int32_t* order = orders ? orders + (size_t)scene * order_cap : nullptr;
@@ -329,13 +332,13 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
         // LDS-DMA (global_load_lds_dwordx4): 1 KiB per wave instruction straight into LDS (destination = uniform base +
         // lane * 16), no VGPR staging, so every piece of the 2 * N / 8 bytes is in flight at once
         const int full = chunks & ~(DMPP_WAVE - 1);
-        for (int c0 = 0; c0 < full; c0 += DMPP_WAVE)
+        for (int c0 = wv * DMPP_WAVE; c0 < full; c0 += kSearchBlock)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src4 + c0 + lane),
                                              (__attribute__((address_space(3))) void*)(dst4 + c0), 16, 0, 0);
-        if (full + lane < chunks) dst4[full + lane] = src4[full + lane];
+        if (wv == 0 && full + lane < chunks) dst4[full + lane] = src4[full + lane];
     }
     __builtin_amdgcn_s_waitcnt(0);             // the bitmaps have landed in LDS and the zeroes of the closed bit set in L2
-    wave_sync();
+    __syncthreads();
 #ifdef DMPP_DEBUG_SEARCH
     const long long t_pack = clock64(); long long t_tr = t_pack, t_nz = t_pack;
 #endif
@@ -352,17 +355,16 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
     long long t0 = clock64(), t_pop = 0, t_closed = 0, t_cand = 0, t_jump = 0, t_push = 0, t_done = 0; int c_iter = 0, c_jobs = 0, c_pass = 0, c_scan = 0, c_nt = 0;
 #endif
 
-    if ((bm[goal >> 5] >> (goal & 31)) & 1u) {
-        status = DMPP_G_GOAL_BLOCKED;
-    } else {
-        if (lane == 0) {                                                    // the vehicle is where it is
+    const bool goal_blocked = ((bm[goal >> 5] >> (goal & 31)) & 1u) != 0;      // the same in every wave
+    if (!goal_blocked) {
+        if (tid == 0) {                                                     // the vehicle is where it is
             const int sx = start % W, sy = start / W;
             start_was_set = (bm[start >> 5] >> (start & 31)) & 1u;
             bm[start >> 5] &= ~(1u << (start & 31));
             bmT[sx * HW + (sy >> 5)] &= ~(1u << (sy & 31));
         }
         if (GBM) __threadfence();
-        wave_sync();
+        __syncthreads();
 #ifdef DMPP_DEBUG_SEARCH
         t_tr = clock64();
 #endif
@@ -372,7 +374,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
             const uint32_t* src = v ? bmT : bm;
             uint32_t* nz = v ? nz_col : nz_row;
             const int LW = v ? HW : WW, NL = v ? W : H, SW = v ? SWc : SWr;
-            for (int line = lane; line < NL; line += DMPP_WAVE) {
+            for (int line = tid; line < NL; line += kSearchBlock) {
                 uint32_t lo = 0, hi = 0;
                 if ((LW & 3) == 0) {
                     const uint4* p4 = reinterpret_cast<const uint4*>(src + line * LW);
@@ -394,13 +396,18 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
 #ifdef DMPP_DEBUG_SEARCH
         t_nz = clock64();
 #endif
-        for (int i = lane; i < kClosedTab; i += DMPP_WAVE) c_tab[i] = 0;
-        if (lane == 0) {
+        for (int i = tid; i < kClosedTab; i += kSearchBlock) c_tab[i] = 0;
+        if (tid == 0) {
             o_ent[0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
             o_f2[0] = (uint16_t)(hfun(start % W, start / W, gx, gy) >> 1);
             o_run[0] = 0;
         }
-        wave_sync();
+    }
+    __syncthreads();
+    if (wv != 0) return;                       // set-up done: the search is wave 0's
+    if (goal_blocked) {
+        status = DMPP_G_GOAL_BLOCKED;
+    } else {
         Bits<GBM> B{ bm, W, H, WW };     // single-cell tests of the diagonal steps
         int n_open = 1, live = 1, fmax = -1;
         n_push = 1;

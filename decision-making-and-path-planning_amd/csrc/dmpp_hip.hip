@@ -504,7 +504,7 @@ int pp_plan_tick(pp_handle h)
         // some 512 workgroups - one scene at 512 x 512: 16 us -> 10 us of the latency-bound tick
         int band_rows = h->raster_band_rows;
         if (!h->raster_band_fixed)
-            while (band_rows > 32 && (long long)n * ((c.grid_h + band_rows - 1) / band_rows) < 512) band_rows /= 2;
+            while (band_rows % 64 == 0 && (long long)n * ((c.grid_h + band_rows - 1) / band_rows) < 512) band_rows /= 2;   // stays a multiple of 32
         const int bands = (c.grid_h + band_rows - 1) / band_rows;
         const size_t lds = 2 * ((size_t)band_rows * c.grid_w / 8);                // the band row-major and column-major
         hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, sf, c, n, band_rows,

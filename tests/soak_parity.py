@@ -38,13 +38,18 @@ def main():
         first = int(rng.integers(0, 1 << 20))
         jevery = int(rng.choice([0, 3, 8]))
         n_ticks = int(rng.integers(1, 6))
-        cfg = dm.default_config(grid)
+        gw = gh = grid
+        if seed0 >= 5 and grid <= 512:                      # seeds from 5 on: any width / height in multiples of 32
+            gw, gh = int(rng.integers(1, 21)) * 32, int(rng.integers(1, 21)) * 32
+        cfg = dm.default_config(gw, gh)
         cfg["dynamic_obstacles"] = dynamic
         cfg["force_replan"] = int(rng.integers(0, 2))
         cfg["decision_stage"] = int(rng.integers(0, 4) != 0)
         cfg["lanechg_stage"] = int(rng.integers(0, 4) != 0)
         sync_each = bool(rng.integers(0, 2))
         sc = dm.gen_scenes(cfg, first, n, n_obs, junction_every=jevery)
+        if gw != gh:                                        # the generator spreads goals over the width
+            sc["scene_in"]["goal"]["y"] = np.clip(sc["scene_in"]["goal"]["y"], 0.0, gh * float(cfg["cell"][0]) - 0.01)
         if rng.integers(0, 3) == 0:
             sc["scene_in"]["period_last"] = float(rng.choice([100.0, 900.0, 1700.0]))
         pl = dm.Planner(cfg, device=0, max_scenes=n, max_obs_total=max(n * n_obs, 1))
@@ -67,7 +72,7 @@ def main():
         pl.close()
         it += 1
         scenes_done += n * n_ticks
-        tag = f"it {it} grid {grid} n {n} obs {n_obs} dyn {dynamic} first {first} jevery {jevery} ticks {n_ticks} sync {int(sync_each)} " \
+        tag = f"it {it} grid {gw}x{gh} n {n} obs {n_obs} dyn {dynamic} first {first} jevery {jevery} ticks {n_ticks} sync {int(sync_each)} " \
               f"dec {int(cfg['decision_stage'][0])} lc {int(cfg['lanechg_stage'][0])} force {int(cfg['force_replan'][0])}"
         if bad:
             bad_total += 1

@@ -552,7 +552,7 @@ def test_back_to_back_ticks_across_config_changes(dm, oracle):
     _assert_tick((pl.get_plan(), pl.get_state(), pl.get_grid_out(), plan_o, st_o, gout_o, None), "after the schedule")
 
 
-@pytest.mark.parametrize("gw,gh", [(96, 160), (224, 64), (32, 32), (640, 384)])
+@pytest.mark.parametrize("gw,gh", [(96, 160), (224, 64), (32, 32), (640, 384), (160, 96)])      # 96 rows: one band that must not be halved
 def test_non_square_grids(dm, oracle, gw, gh):
     """Line widths that are not a power of two (3, 7, 20 words), very small and non-square grids: the word summaries,
     the band layout of the rasteriser and the candidate-word scans must not depend on the 512 x 512 shape."""

@@ -52,17 +52,27 @@ def main():
             sc["scene_in"]["goal"]["y"] = np.clip(sc["scene_in"]["goal"]["y"], 0.0, gh * float(cfg["cell"][0]) - 0.01)
         if rng.integers(0, 3) == 0:
             sc["scene_in"]["period_last"] = float(rng.choice([100.0, 900.0, 1700.0]))
+        one_shot = bool(rng.integers(0, 3) == 0)            # host buffers through pp_plan_tick_batch, state carried by the caller
         pl = dm.Planner(cfg, device=0, max_scenes=n, max_obs_total=max(n * n_obs, 1))
         pl.set_state(sc["state"])
         st_o = sc["state"].copy()
+        st_h = sc["state"].copy()
         bad = []
         for t in range(n_ticks):
             if t and rng.integers(0, 2):
                 move_ego(sc, int(rng.integers(1, 9)), dlat=float(rng.choice([0.0, 0.2, -0.4])))
-            pl.set_scenes(sc)
-            pl.tick(sync=sync_each)
+            if one_shot:
+                plan_g, gout_g = pl.plan_tick_batch(sc, st_h)
+            else:
+                pl.set_scenes(sc)
+                pl.tick(sync=sync_each)
             plan_o, gout_o, _ = orc.plan_tick_batch(cfg, sc, st_o, n_threads=threads, want_grid=True)
-            if sync_each or t == n_ticks - 1:
+            if one_shot:
+                bad += compare(plan_g, plan_o, "plan") + compare(st_h, st_o, "state")
+                bad += compare(gout_g["status"], gout_o["status"], "grid.status")
+                keep = gout_o["status"] != 3
+                bad += compare(gout_g[keep], gout_o[keep], "grid")
+            elif sync_each or t == n_ticks - 1:
                 pl.sync()
                 plan_g, st_g, gout_g = pl.get_plan(), pl.get_state(), pl.get_grid_out()
                 bad += compare(plan_g, plan_o, "plan") + compare(st_g, st_o, "state")
@@ -72,7 +82,7 @@ def main():
         pl.close()
         it += 1
         scenes_done += n * n_ticks
-        tag = f"it {it} grid {gw}x{gh} n {n} obs {n_obs} dyn {dynamic} first {first} jevery {jevery} ticks {n_ticks} sync {int(sync_each)} " \
+        tag = f"it {it} grid {gw}x{gh} n {n} obs {n_obs} dyn {dynamic} first {first} jevery {jevery} ticks {n_ticks} sync {int(sync_each)} oneshot {int(one_shot)} " \
               f"dec {int(cfg['decision_stage'][0])} lc {int(cfg['lanechg_stage'][0])} force {int(cfg['force_replan'][0])}"
         if bad:
             bad_total += 1

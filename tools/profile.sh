@@ -2,12 +2,13 @@
 # Runs ON THE GPU BOX (through gpurun): kernel-trace stats + the two PMC passes of the guide
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950; --pmc never together with sys/hip traces).
 #   gpurun --timeout 900 -- 'bash tools/profile.sh r1'
+#   gpurun --timeout 900 -- 'bash tools/profile.sh r1_c4 --grid 2048'        (extra bench.py arguments after the tag)
 # Results land in gpurun_out/prof_<tag>_*; copy the summaries into profiles/ with tools/profile_summary.py.
 set -e
 TAG=${1:-r1}
 export TMPDIR=/tmp
 R=$PWD
-ARGS="--no-cpu-baseline --latency-ticks 0"
+ARGS="--no-cpu-baseline --latency-ticks 0 ${@:2}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats -- python3 bench.py --steps 10 --warmup 2 $ARGS > gpurun_out/prof_${TAG}_stats.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_fetch -- python3 bench.py --steps 3 --warmup 1 $ARGS > gpurun_out/prof_${TAG}_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_write -- python3 bench.py --steps 3 --warmup 1 $ARGS > gpurun_out/prof_${TAG}_write.log 2>&1

@@ -139,6 +139,17 @@ int drain_events(pp_planner* h)
     return PP_OK;
 }
 
+// Rows per band of k_rasterise.  128 whole rows is the measured optimum for batches that fill the chip (16-byte pieces
+// of the column-major bitmap per column and band); a handful of scenes gets narrower bands - halved while the result
+// stays a multiple of 32 rows - until there are some 512 workgroups (one scene at 512 x 512: 16 us -> 10 us).
+int raster_band_rows_for(int grid_h, int n_scenes, int base)
+{
+    int band = base < 32 ? 32 : base / 32 * 32;
+    if (band > grid_h) band = grid_h;
+    while (band % 64 == 0 && (long long)n_scenes * ((grid_h + band - 1) / band) < 512) band /= 2;
+    return band;
+}
+
 int setup_grid_launch(pp_planner* h)
 {
     const PlannerConfig& c = h->cfg;
@@ -502,9 +513,7 @@ int pp_plan_tick(pp_handle h)
         Timed t(h, PP_K_RASTERISE, sf);
         // a handful of scenes does not fill the chip with 128-row bands: halve the bands (down to 32 rows) until there are
         // some 512 workgroups - one scene at 512 x 512: 16 us -> 10 us of the latency-bound tick
-        int band_rows = h->raster_band_rows;
-        if (!h->raster_band_fixed)
-            while (band_rows % 64 == 0 && (long long)n * ((c.grid_h + band_rows - 1) / band_rows) < 512) band_rows /= 2;   // stays a multiple of 32
+        const int band_rows = h->raster_band_fixed ? h->raster_band_rows : raster_band_rows_for(c.grid_h, n, h->raster_band_rows);
         const int bands = (c.grid_h + band_rows - 1) / band_rows;
         const size_t lds = 2 * ((size_t)band_rows * c.grid_w / 8);                // the band row-major and column-major
         hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, sf, c, n, band_rows,
@@ -894,6 +903,8 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes)
     return p;
 }
 void* pp_stream(pp_handle h) { return h ? (void*)h->stream : nullptr; }
+
+int pp_raster_band_rows(int grid_h, int n_scenes) { return raster_band_rows_for(grid_h, n_scenes, 128); }
 
 size_t pp_sizeof(int which)
 {

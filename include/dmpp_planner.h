@@ -157,6 +157,10 @@ void* pp_stream(pp_handle h);       /* hipStream_t */
  * 2 SceneIn, 3 SceneState, 4 PlanOut, 5 GridOut, 6 ObPoint, 7 ObMotion, 8 Path_Obs, 9 LocationOut,
  * 10 DecisionOut, 11 LaneView, 12 PlanningOut, 13 PlanningStatus, 14 AimPoint */
 size_t pp_sizeof(int which);
+/* Host-side launch geometry, callable without a GPU (tests): rows per band of the rasteriser for a grid of grid_h rows
+ * and a batch of n_scenes (128 for large batches, narrower - always a multiple of 32 - when the batch does not fill
+ * the chip). */
+int   pp_raster_band_rows(int grid_h, int n_scenes);
 int   pp_set_n_scenes(pp_handle h, int n_scenes);  /* after filling the buffers through pp_device_ptr */
 
 #ifdef __cplusplus

@@ -519,6 +519,12 @@ int pp_plan_tick(pp_handle h)
         hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, sf, c, n, band_rows,
                            h->d_in, obs_now, h->d_gbm[p]);
     }
+    // launch order of the search (heaviest scenes first) - pointless while every scene is resident at once (2 per CU).
+    // In the three-chain tick it is computed here, on the front chain, from the search of tick t-2 (certainly complete:
+    // this chain has waited for it), so that nothing stands between two consecutive searches on their stream.
+    const bool order_scenes = c.grid_stage && n > kSearchSlots;
+    const bool order_in_front = order_scenes && piped;
+    if (order_in_front) hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sf, n, h->d_cost[p], h->d_perm[p]);
     if (sf != sm) HIP_TRY(hipEventRecord(h->ev_raster, sf));
     if (c.decision_stage) {
         Timed t(h, PP_K_DECISION, sr);
@@ -535,10 +541,9 @@ int pp_plan_tick(pp_handle h)
         if (sf != sm) HIP_TRY(hipStreamWaitEvent(sm, h->ev_raster, 0));
         {
             Timed t(h, PP_K_SEARCH, sm);
-            // heaviest scenes first (by last tick's cost) - pointless while every scene is resident at once (2 waves per CU)
-            // keyed by the last search that is certainly complete: the previous tick's, or - when consecutive searches overlap - the one before
-            const int32_t* perm = n > kSearchSlots ? h->d_perm[p] : nullptr;
-            if (perm) hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[overlap ? p : p ^ 1], h->d_perm[p]);
+            const int32_t* perm = order_scenes ? h->d_perm[p] : nullptr;
+            if (perm && !order_in_front)          // one-stream tick with more scenes than search slots (DMPP_PIPELINE_MIN raised): keyed by the previous tick
+                hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[p ^ 1], h->d_perm[p]);
             if (h->search_gbm)
                 hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(dmpp::kSearchBlock), (size_t)h->search_lds, sm, c, n, h->caps.order_cap, perm, h->d_in,
                                    h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost[p]);

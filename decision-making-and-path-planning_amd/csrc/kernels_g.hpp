@@ -894,7 +894,7 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
         return bz;
     };
     // ---- obstacles that can matter at all: inside the box of every candidate grown by their cutoff.
-    //      A Bezier lies in the hull of its control points; the grid path stays within a+1 cells of the ego.
+    //      A Bezier lies in the hull of its control points; the grid path stays within a+1 cells of its first cell.
     if (tid < nl) {
         double off; const Bezier bz = lattice_curve(tid, off);
         sh.bx0[tid] = fmin(fmin(bz.x0, bz.x1), fmin(bz.x2, bz.x3)); sh.bx1[tid] = fmax(fmax(bz.x0, bz.x1), fmax(bz.x2, bz.x3));
@@ -905,8 +905,11 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
     double X0 = __builtin_inf(), X1 = -__builtin_inf(), Y0 = __builtin_inf(), Y1 = -__builtin_inf();
     for (int k = 0; k < nl; k++) { X0 = fmin(X0, sh.bx0[k]); X1 = fmax(X1, sh.bx1[k]); Y0 = fmin(Y0, sh.by0[k]); Y1 = fmax(Y1, sh.by1[k]); }
     if (have_path) {
+        // around the centre of the path's first cell, not around the ego: an ego outside the grid is clamped to a border cell
         const double ext = (double)(a + 2) * c.cell;
-        X0 = fmin(X0, ego.x - ext); X1 = fmax(X1, ego.x + ext); Y0 = fmin(Y0, ego.y - ext); Y1 = fmax(Y1, ego.y + ext);
+        const int pc0 = path[0];
+        const double px0 = si.grid_origin.x + ((double)(pc0 % W) + 0.5) * c.cell, py0 = si.grid_origin.y + ((double)(pc0 / W) + 0.5) * c.cell;
+        X0 = fmin(X0, px0 - ext); X1 = fmax(X1, px0 + ext); Y0 = fmin(Y0, py0 - ext); Y1 = fmax(Y1, py0 + ext);
     }
     const bool culled = m <= kMaxObsLds;          // longer lists are read from HBM without culling
     if (culled) {

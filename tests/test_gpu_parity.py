@@ -632,3 +632,24 @@ def test_bench_two_ranks_rehearsal(dm, oracle):
     for _ in range(4):
         _, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st, n_threads=8, want_grid=True)
     assert line["search_status_counts"] == np.bincount(gout_o["status"], minlength=6).tolist()
+
+
+@pytest.mark.parametrize("dx,dy", [(25.0, 0.0), (-30.0, 0.0), (0.0, -40.0)])
+def test_ego_outside_the_grid(dm, oracle, dx, dy):
+    """An ego outside its grid starts the search from a clamped border cell, far from where it stands: the scoring
+    kernel's obstacle culling must follow the path, not the ego (found by tests/soak_parity.py: with the box around
+    the ego, an obstacle beside the far part of the path was dropped from the path candidate's penalty)."""
+    cfg = dm.default_config(64, 384)
+    n = 512
+    sc = dm.gen_scenes(cfg, 4242, n, 130, junction_every=3)
+    si = sc["scene_in"]
+    si["goal"]["y"] = np.clip(si["goal"]["y"], 0.0, 384 * float(cfg["cell"][0]) - 0.01)
+    si["grid_origin"]["x"] += dx
+    si["grid_origin"]["y"] += dy
+    pl = dm.Planner(cfg, max_scenes=n, max_obs_total=n * 130)
+    st_g, st_o = sc["state"].copy(), sc["state"].copy()
+    plan_g, gout_g = pl.plan_tick_batch(sc, st_g)
+    plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st_o, n_threads=8, want_grid=True)
+    bad = compare(gout_g, gout_o, "grid") + compare(plan_g, plan_o, "plan") + compare(st_g, st_o, "state")
+    assert not bad, "\n".join(bad[:10])
+    assert int((gout_o["status"] == dm.G_FOUND).sum()) >= 20

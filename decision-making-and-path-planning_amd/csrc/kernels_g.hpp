@@ -1007,11 +1007,11 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
     {   // regenerate the winner into the output
         const int k = sh.best;
         if (tid < DMPP_PATH_POINTS) {
-            GlobalPoint2D p;
+            GlobalPoint2D p = { 0.0, 0.0 };                 // no candidate at all (n_lattice = 0 and no grid path): zeros
             if (k < nl) {
                 double off; const Bezier bz = lattice_curve(k, off);
                 p = bezier_point(bz, tid, DMPP_PATH_POINTS);
-            } else p = mean_point(c, sh.pts, sh.cum, a + 1, tid, DMPP_PATH_POINTS);
+            } else if (nc > 0) p = mean_point(c, sh.pts, sh.cum, a + 1, tid, DMPP_PATH_POINTS);
             go.best_path[tid] = p;
         }
     }

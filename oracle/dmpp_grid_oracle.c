@@ -363,6 +363,7 @@ void orc_grid_score(const PlannerConfig* c, const SceneIn* in, const ObPoint* ob
     int nl = c->n_lattice; if (nl > DMPP_MAX_LATTICE - 1) nl = DMPP_MAX_LATTICE - 1;
     int nc = nl + (have_path ? 1 : 0);
     out->n_candidates = nc;
+    if (nc == 0) memset(out->best_path, 0, sizeof(out->best_path));     /* nothing to choose from: zeros, best_candidate 0 */
     double th = thT * c->PI / 180, cs = cos(th), sn = sin(th);
     double best = 0; int bi = 0;
     GlobalPoint2D cand[DMPP_PATH_POINTS];

@@ -46,10 +46,31 @@ def main():
         cfg["force_replan"] = int(rng.integers(0, 2))
         cfg["decision_stage"] = int(rng.integers(0, 4) != 0)
         cfg["lanechg_stage"] = int(rng.integers(0, 4) != 0)
+        if seed0 >= 14:                                     # seeds from 14 on: the limits and weights of the grid engine as well
+            if rng.integers(0, 4) == 0:
+                cfg["max_expansions"] = int(rng.choice([1, 7, 40, 100, 300]))
+            if rng.integers(0, 4) == 0:
+                cfg["bucket_cap"] = int(rng.choice([16, 24, 40, 100]))
+            if rng.integers(0, 4) == 0:
+                cfg["max_path"] = int(rng.choice([2, 17, 100, 250]))
+            if rng.integers(0, 3) == 0:
+                cfg["n_lattice"] = int(rng.integers(0, 17))
+            if rng.integers(0, 3) == 0:
+                cfg["lookahead_cells"] = int(rng.choice([1, 5, 40, 120, 199, 400]))
+            if rng.integers(0, 4) == 0:
+                cfg["inflate"] = float(rng.choice([0.0, 0.3, 1.1]))
+            if rng.integers(0, 4) == 0:
+                cfg["d_safe"] = float(rng.choice([0.2, 1.0, 3.0]))
+            if rng.integers(0, 4) == 0:
+                cfg["ID_MORE"] = int(rng.integers(0, 6))
         sync_each = bool(rng.integers(0, 2))
         sc = dm.gen_scenes(cfg, first, n, n_obs, junction_every=jevery)
         if gw != gh:                                        # the generator spreads goals over the width
             sc["scene_in"]["goal"]["y"] = np.clip(sc["scene_in"]["goal"]["y"], 0.0, gh * float(cfg["cell"][0]) - 0.01)
+        if seed0 >= 14 and rng.integers(0, 3) == 0:         # egos (and goals) outside their grids: clamped start / goal cells
+            k = len(sc["scene_in"])
+            sc["scene_in"]["grid_origin"]["x"] += rng.choice([0.0, 0.0, 7.0, -9.0, 30.0], size=k)
+            sc["scene_in"]["grid_origin"]["y"] += rng.choice([0.0, 0.0, 5.0, -12.0, -40.0], size=k)
         if rng.integers(0, 3) == 0:
             sc["scene_in"]["period_last"] = float(rng.choice([100.0, 900.0, 1700.0]))
         one_shot = bool(rng.integers(0, 3) == 0)            # host buffers through pp_plan_tick_batch, state carried by the caller

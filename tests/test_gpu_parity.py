@@ -653,3 +653,18 @@ def test_ego_outside_the_grid(dm, oracle, dx, dy):
     bad = compare(gout_g, gout_o, "grid") + compare(plan_g, plan_o, "plan") + compare(st_g, st_o, "state")
     assert not bad, "\n".join(bad[:10])
     assert int((gout_o["status"] == dm.G_FOUND).sum()) >= 20
+
+
+def test_no_candidate_at_all(dm, oracle):
+    """n_lattice = 0 leaves the grid path as the only candidate; a scene without a path then has none: n_candidates 0,
+    best_candidate 0 and a best_path of zeros (found by tests/soak_parity.py: the kernel resampled an empty path)."""
+    cfg = dm.default_config(128)
+    cfg["n_lattice"] = 0
+    sc = dm.gen_scenes(cfg, 5150, 200, 24, junction_every=0)
+    pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=2)
+    for t, r in enumerate(res):
+        _assert_tick(r, f"tick {t}")
+    gout_o = res[-1][5]
+    none = gout_o["n_candidates"] == 0
+    assert none.any() and (~none).any(), np.bincount(gout_o["status"])
+    assert not gout_o["best_path"]["x"][none].any()

@@ -71,6 +71,22 @@ def main():
             k = len(sc["scene_in"])
             sc["scene_in"]["grid_origin"]["x"] += rng.choice([0.0, 0.0, 7.0, -9.0, 30.0], size=k)
             sc["scene_in"]["grid_origin"]["y"] += rng.choice([0.0, 0.0, 5.0, -12.0, -40.0], size=k)
+        if seed0 >= 18 and rng.integers(0, 2) == 0:         # ragged road inputs on a random subset of the scenes (cf. test_edge_cases)
+            si = sc["scene_in"]
+            k = len(si)
+            pick = lambda frac: rng.random(k) < frac
+            m = pick(0.15); si["lanes"]["lane_width"][m] = 7.0
+            m = pick(0.3); si["lanes"]["lanechg_attribute"][m] = rng.integers(0, 4, size=int(m.sum()))
+            m = pick(0.1); si["ref_n"][m] = 2; si["dec"]["refpath_n"][m] = 2
+            m = pick(0.1); si["ref_n"][m] = 0; si["dec"]["refpath_n"][m] = 0
+            m = pick(0.1); si["loc"]["id"][m] = dm.GEN_LANE_PTS - 2
+            m = pick(0.05); si["loc"]["id"][m] = dm.GEN_LANE_PTS + 5
+            m = pick(0.05); si["lanes"]["cur_n"][m] = 1
+            m = pick(0.1); si["lanes"]["left_n"][m] = 0
+            m = pick(0.1); si["lanes"]["right_n"][m] = 0
+            m = pick(0.1); si["obs_n"][m] = 0
+            m = pick(0.1); si["obs_n"][m] = np.minimum(si["obs_n"][m], 3)
+            m = pick(0.1); si["loc"]["velocity"][m] = rng.choice([0.0, 0.5, 35.0], size=int(m.sum()))
         if rng.integers(0, 3) == 0:
             sc["scene_in"]["period_last"] = float(rng.choice([100.0, 900.0, 1700.0]))
         one_shot = bool(rng.integers(0, 3) == 0)            # host buffers through pp_plan_tick_batch, state carried by the caller

@@ -2,28 +2,34 @@
 """bench.py — planning ticks/s on batched synthetic scenes (BASELINE.json metric).
 
 A "step" is one Decision+Planning+grid tick (pp_plan_tick) over one resident batch of scenes:
-BASELINE configs[1] — 1024 scenes, 512x512 occupancy grid, 64 obstacles — per GPU.  With
---gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the scenes of all ranks are
-generated on rank 0 and SCATTERED over RCCL, every rank ticks its own shard with no data-path
-collective (scenes are independent: weak scaling, configs[2] at N = 8), and the per-scene
-digests are GATHERED back over RCCL for a cross-rank check.  Scatter/gather are outside the
-timed region (inputs resident in HBM when timing starts).
+BASELINE configs[1] — 1024 scenes, 512x512 occupancy grid, 64 obstacles — per GPU.
+
+N > 1 (BASELINE configs[2] at N = 8): one process per GPU.  Either the driver starts the ranks
+(`python -m torch.distributed.run ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) or a plain `python bench.py --gpus N` starts them itself: the parent, which never imports torch or
+loads libdmpp.so (no HIP call, so nothing that has touched a GPU is forked or exec'ed), starts N fresh children
+with that environment, relays rank 0's JSON line and exits non-zero if any child does.  The scenes of all ranks
+are generated on rank 0 and SCATTERED over RCCL, every rank ticks its own shard with no data-path collective
+(scenes are independent: weak scaling), and PlanOut + SceneState + GridOut of every scene are GATHERED back to
+rank 0 over RCCL, where every shard is checked bit for bit against a single-GPU run of the same
+scenes.  Scatter / gather / check are outside the timed region (inputs resident in HBM when timing starts).
 
 Timing: W warm-up steps, barrier + device sync, K steps, barrier + device sync, MAX over ranks.
-Per-kernel durations come from HIP events recorded by the library on its own stream.
+Per-kernel durations come from HIP events recorded by the library on the streams its kernels run on.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+GRID_KERNELS = ("k_effective_obstacles", "k_rasterise", "k_order", "k_search", "k_score")
 
 
 def parse():
@@ -40,7 +46,41 @@ def parse():
     ap.add_argument("--latency-ticks", type=int, default=200)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path with ranks sharing the GPUs of a smaller box (never a measured number)")
+    ap.add_argument("--dump-gathered", default=None, help="rank 0 writes the gathered PlanOut / SceneState / GridOut of all ranks to this .npz (tests)")
+    ap.add_argument("--no-verify-gather", action="store_true", help="skip the bit-for-bit check of the gathered shards on rank 0")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# plain `python bench.py --gpus N`: this process only starts the ranks (no torch, no HIP in here)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n_ranks):
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    for ln in (out0 or "").splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if any(codes) or not lines:
+        print("bench.py: rank exit codes %s, %d result line(s)" % (codes, len(lines)), file=sys.stderr)
+        return max([c for c in codes if c > 0] + [1])
+    print(lines[-1])
+    return 0
 
 
 def algorithmic_bytes(cfg, n_obs):
@@ -52,6 +92,7 @@ def algorithmic_bytes(cfg, n_obs):
         "k_effective_obstacles": 2 * 24 * n_obs,
         "k_decision": 480 * 24 + 24 * n_obs + 6 * 48 + 120 * 16,
         "k_planning": b_r,
+        "k_front": 480 * 24 + 24 * n_obs + 6 * 48 + 120 * 16 + b_r,   # Decision + Planning in one launch
         "k_rasterise": W * H + 24 * n_obs,           # one write per cell (the device writes it bit-packed, twice: W*H/4 bytes)
         "k_search": W * H + 3200,                    # one read per cell + the path out (read bit-packed: W*H/4 bytes)
         "k_score": 24 * n_obs + 3200 + 3200,
@@ -61,9 +102,12 @@ def algorithmic_bytes(cfg, n_obs):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
     import torch
     import dmpp_amd as dm
 
@@ -74,6 +118,9 @@ def main():
     rehearsal = args.backend != "nccl"
     if rehearsal:
         local_rank %= torch.cuda.device_count()
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, this box shows %d (use --backend gloo to rehearse)"
+                         % (world, world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     comm_dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
@@ -94,13 +141,14 @@ def main():
     pl = dm.Planner(cfg, device=local_rank, max_scenes=n, max_obs_total=max(n * n_obs, 1))
 
     # ---- inputs: generated on rank 0, scattered over RCCL, handed to the library as device pointers ----
+    scatter_ms = None
     if world == 1:
         sc = dm.gen_scenes(cfg, 0, n, n_obs, junction_every=8)
         pl.set_scenes(sc)
         pl.set_state(sc["state"])
     else:
         from dmpp_amd_pkg import sharding
-        recv = sharding.scatter_scenes(dm, dist, torch, cfg, n, n_obs, rank, world, comm_dev)
+        recv, scatter_ms = sharding.scatter_scenes(dm, dist, torch, cfg, n, n_obs, rank, world, comm_dev, timed=True)
         recv = {k: v.cuda() for k, v in recv.items()}
         torch.cuda.synchronize()
         lib = pl.lib
@@ -112,7 +160,7 @@ def main():
         pl.n = n
 
     def barrier():
-        pl.sync()                       # the library's own stream
+        pl.sync()                       # the library's own streams
         torch.cuda.synchronize()        # everything else on this device
         if dist is not None:
             dist.barrier()
@@ -127,7 +175,7 @@ def main():
     for _ in range(args.steps):
         pl.tick()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
     kms = pl.kernel_ms()
     pl.set_profile(False)
     if dist is not None:
@@ -135,15 +183,68 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- results gathered over RCCL (digest check on rank 0) ----
+    b_r, b_g, per_kernel = algorithmic_bytes(cfg, n_obs)
+
+    def roofline_of(kms_):
+        dom = max(kms_, key=lambda k: kms_[k][0])
+        dom_ms, dom_launches = kms_[dom]
+        avg_ms = dom_ms / max(dom_launches, 1)
+        achieved = per_kernel[dom] * n / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        return dom, avg_ms, achieved
+
+    # ---- results gathered over RCCL: PlanOut + SceneState + GridOut of every scene, checked on rank 0 ----
     gout = pl.get_grid_out()
+    gathered = None
+    multi = None
     if dist is not None:
         from dmpp_amd_pkg import sharding
-        mine = torch.from_numpy(gout["order_digest"].astype(np.int64)).to(comm_dev)
-        allg = sharding.gather_results(dist, torch, mine, rank, world)
+        mine = sharding.result_tensors(dm, torch, pl, n, comm_dev)      # device-to-device copies out of the handle's buffers
         torch.cuda.synchronize()
+        if not rehearsal:
+            dist.barrier()
+        g0 = time.perf_counter()
+        allg = {k: sharding.gather_results(dist, torch, v, rank, world) for k, v in mine.items()}
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        dom, avg_ms, achieved = roofline_of(kms)
+        stats = [None] * world
+        dist.all_gather_object(stats, {"rank": rank, "ms_per_step": dt_local / args.steps * 1e3, "kernel": dom, "avg_launch_ms": avg_ms,
+                                       "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS,
+                                       "search_status_counts": np.bincount(gout["status"], minlength=6).tolist()})
         if rank == 0:
-            assert len(allg) == world and all(t.numel() == n for t in allg)
+            dts = {"plan": dm.PlanOut, "state": dm.SceneState, "grid_out": dm.GridOut}
+            gathered = {k: [np.frombuffer(t.cpu().numpy().tobytes(), dts[k]) for t in allg[k]] for k in dts}
+            gathered_bytes = sum(t.numel() for k in allg for t in allg[k])
+            checked, mism = 0, []
+            if not args.no_verify_gather:
+                # every shard again on THIS GPU alone, the same W + K ticks from the same generated scenes: the gathered
+                # records must be identical (integers and floats bit for bit; NaN == NaN)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from parity_util import compare
+                plv = dm.Planner(cfg, device=local_rank, max_scenes=n, max_obs_total=max(n * n_obs, 1))
+                for r in range(world):
+                    scr = dm.gen_scenes(cfg, r * n, n, n_obs, junction_every=8)
+                    plv.set_scenes(scr)
+                    plv.set_state(scr["state"])
+                    for _ in range(args.warmup + args.steps):
+                        plv.tick()
+                    plv.sync()
+                    want = {"plan": plv.get_plan(), "state": plv.get_state(), "grid_out": plv.get_grid_out()}
+                    for k in want:
+                        mism += ["rank %d %s" % (r, m) for m in compare(gathered[k][r], want[k], k, rtol=0.0, atol=0.0)]
+                    checked += 1
+                plv.close()
+                if mism:
+                    print("bench.py: gathered results differ from a single-GPU run:\n" + "\n".join(mism[:10]), file=sys.stderr)
+            multi = {"scatter_ms": scatter_ms, "gather_ms": gather_ms, "gathered_bytes": gathered_bytes,
+                     "gathered_records": "PlanOut + SceneState + GridOut per scene (%d B)" % (dm.PlanOut.itemsize + dm.SceneState.itemsize + dm.GridOut.itemsize),
+                     "shards_verified": checked, "shard_mismatches": len(mism), "per_rank": stats}
+            if args.dump_gathered:
+                np.savez(args.dump_gathered, **{k: np.concatenate(v) for k, v in gathered.items()})
+            if mism:
+                pl.close()
+                dist.destroy_process_group()
+                sys.exit(3)
 
     # ---- Part R alone (Decision + Planning ticks, grid engine off) on the same scenes, rank 0; SURVEY 8(d) asks for
     #      the two parts separately as well as combined.  Part G's kernels never run without Part R's inputs, so its
@@ -162,13 +263,18 @@ def main():
         pl.sync()
         r_dt = time.perf_counter() - r0
         pl.set_config(cfg)
-        g_ms = sum(v[0] / max(v[1], 1) for k, v in kms.items() if k in ("k_effective_obstacles", "k_rasterise", "k_order", "k_search", "k_score"))
+        g_ms = sum(v[0] / max(v[1], 1) for k, v in kms.items() if k in GRID_KERNELS)
+        front_ms = sum(v[0] / max(v[1], 1) for k, v in kms.items() if k in ("k_effective_obstacles", "k_rasterise", "k_decision", "k_planning", "k_front"))
         parts = {"R_only_ticks_per_s": n * args.steps / r_dt, "R_only_ms_per_step": r_dt / args.steps * 1e3,
                  "G_kernels_serial_ms": g_ms, "G_kernels_serial_ticks_per_s": (n / (g_ms * 1e-3)) if g_ms > 0 else None,
-                 "note": "per GPU; R = k_decision + k_planning with the grid stage off; G = sum of the grid-engine kernels' average launch times inside the combined tick"}
+                 "front_chain_ms": front_ms,
+                 "note": "per GPU; R = Decision + Planning with the grid stage off; G = sum of the grid-engine kernels' average launch times "
+                         "inside the combined tick; front_chain = obstacle snapshot + rasterise + Decision + Planning, the kernels that share one stream beside the search"}
 
-    # ---- p50 plan latency, batch = 1 (rank 0) ----
+    # ---- p50 plan latency, batch = 1 (rank 0): the C-ABI tick, and the C++ class surface CDecision::decide -> CPlanning::plan ----
     p50_ms = None
+    p50_class_ms = None
+    sc1 = None
     if rank == 0 and args.latency_ticks > 0:
         pl1 = dm.Planner(cfg, device=local_rank, max_scenes=1, max_obs_total=max(n_obs, 1))
         sc1 = dm.gen_scenes(cfg, 0, 1, n_obs, junction_every=0)
@@ -183,6 +289,11 @@ def main():
             lat.append((time.perf_counter() - a) * 1e3)
         p50_ms = float(np.percentile(lat, 50))
         pl1.close()
+        try:
+            from dmpp_amd_pkg import host_surface
+            p50_class_ms = host_surface.p50_plan_ms(dm, cfg, sc1, device=local_rank, ticks=args.latency_ticks)
+        except (ImportError, OSError) as e:          # the C++ host library is optional for the bench (never for the tests)
+            print("bench.py: class-surface latency skipped: %s" % e, file=sys.stderr)
 
     # ---- CPU baseline: the oracle (a port of the path), timed on this box's host cores ----
     cpu = None
@@ -223,30 +334,50 @@ def main():
         one_ticks = 20
         orc.plan_tick_batch(cfg, sc1t, st1, n_threads=1, n_ticks=one_ticks)
         one_dt = time.perf_counter() - one0
+        # p50 latency of ONE scene on one thread: the scene the GPU's batch-1 latency is measured on
+        cpu_p50 = None
+        if args.latency_ticks > 0:
+            scl = sc1 if sc1 is not None else dm.gen_scenes(cfg, 0, 1, n_obs, junction_every=0)
+            stl = scl["state"].copy()
+            for _ in range(3):
+                orc.plan_tick_batch(cfg, scl, stl, n_threads=1)
+            clat = []
+            for _ in range(min(args.latency_ticks, 100)):
+                a = time.perf_counter()
+                orc.plan_tick_batch(cfg, scl, stl, n_threads=1)
+                clat.append((time.perf_counter() - a) * 1e3)
+            cpu_p50 = float(np.percentile(clat, 50))
         cpu = {"value": n * ticks / cdt, "unit": "ticks/s", "cores": cores, "kind": "port",
-               "single_thread_ticks_per_s": ns1 * one_ticks / one_dt, "cpu_count": ncpu, "cgroup_cpu_quota": quota,
+               "single_thread_ticks_per_s": ns1 * one_ticks / one_dt, "p50_ms_batch1": cpu_p50,
+               "cpu_count": ncpu, "cgroup_cpu_quota": quota,
                "sample": f"{ticks} consecutive ticks x {n} scenes of the same workload ({args.grid}x{args.grid}, {n_obs} obstacles), "
-                         f"oracle C port, {cores} pthreads (fastest of 8..{ncpu} on this box: os.cpu_count() = {ncpu}, cgroup CPU quota = {quota}) each ticking its own block of scenes, {cdt:.1f} s"}
+                         f"oracle C port, {cores} pthreads (fastest of 8..{ncpu} on this box: os.cpu_count() = {ncpu}, cgroup CPU quota = {quota}) each ticking its own block of scenes, {cdt:.1f} s; "
+                         f"p50_ms_batch1 = one scene (seed 0, the scene of p50_plan_latency_ms_batch1), one thread, one tick per call"}
 
     if rank == 0:
-        b_r, b_g, per_kernel = algorithmic_bytes(cfg, n_obs)
-        dom = max(kms, key=lambda k: kms[k][0])
-        dom_ms, dom_launches = kms[dom]
-        avg_ms = dom_ms / max(dom_launches, 1)
-        achieved = per_kernel[dom] * n / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        dom, avg_ms, achieved = roofline_of(kms)
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/profile.sh:
         # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload; FETCH_SIZE doubled per the
         # gfx950 note of MI355X_MICROARCH.md).  Only quoted for the workload it was measured on.
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r1_pmc.json")
-        if os.path.exists(pmc_path) and n == 1024 and args.grid == 512 and n_obs == 64 and not args.dynamic:
-            pmc = json.load(open(pmc_path))["kernels"]
-            for name, k in pmc.items():
-                if name.split("<")[0] == dom and "hbm_bytes_gfx950_corrected" in k:
-                    traffic, traffic_src = k["hbm_bytes_gfx950_corrected"], "profiles/r1_pmc.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
+        tag = None
+        if n == 1024 and n_obs == 64 and not args.dynamic and args.grid in (512, 2048):
+            tag = "r2" if args.grid == 512 else "r2_c4"
+        for cand in ([tag, tag.replace("r2", "r1")] if tag else []):
+            pmc_path = os.path.join(ROOT, "profiles", cand + "_pmc.json")
+            if traffic is None and os.path.exists(pmc_path):
+                pmc = json.load(open(pmc_path))["kernels"]
+                for name, k in pmc.items():
+                    if name.split("<")[0] == dom and "hbm_bytes_gfx950_corrected" in k:
+                        traffic, traffic_src = k["hbm_bytes_gfx950_corrected"], "profiles/%s_pmc.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)" % cand
+        status_counts = np.bincount(gout["status"], minlength=6)
+        if multi:
+            status_counts = np.sum([s["search_status_counts"] for s in multi["per_rank"]], axis=0)
+        searched = int(status_counts.sum() - status_counts[dm.G_GOAL_BLOCKED])
+        total = n * world
         line = {
             "metric": "planning ticks/sec (batched scenes), %dx%d grid" % (args.grid, args.grid),
-            "value": n * world * args.steps / dt,
+            "value": total * args.steps / dt,
             "unit": "ticks/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -258,27 +389,35 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %d scenes/GPU, %dx%d grid, %d %s obstacles"
-                                   % (3 if args.dynamic else (2 if world > 1 else 1), n, args.grid, args.grid, n_obs,
+                                   % (3 if args.dynamic else (4 if args.grid == 2048 else (2 if world > 1 else 1)), n, args.grid, args.grid, n_obs,
                                       "dynamic" if args.dynamic else "static"),
-                       "scenes_per_gpu": n, "global_scenes": n * world, "grid": args.grid, "obstacles": n_obs,
+                       "scenes_per_gpu": n, "global_scenes": total, "grid": args.grid, "obstacles": n_obs,
                        "parallelism": ("scene-sharded x%d, RCCL scatter/gather outside the timed region" % world)
                                       + (" [REHEARSAL: gloo, ranks share GPUs - not a measurement]" if rehearsal else ""),
                        "algorithmic_bytes_per_tick": b_r + b_g,
-                       "tick_GBps": (b_r + b_g) * n * world * args.steps / dt / 1e9},
+                       "tick_GBps": (b_r + b_g) * total * args.steps / dt / 1e9},
             "p50_plan_latency_ms_batch1": p50_ms,
+            "p50_class_surface_ms": p50_class_ms,
             "parts": parts,
-            "search_status_counts": np.bincount(gout["status"], minlength=6).tolist(),
-            "kernel_ms_avg": {k: (v[0] / max(v[1], 1)) for k, v in kms.items()},
+            "search_status_counts": [int(v) for v in status_counts],
+            # scenes whose goal cell is occupied end with GOAL_BLOCKED before any expansion: they are ticks (Decision, Planning,
+            # rasterise and scoring run) but no search - the rate over the scenes that did search is quoted beside the headline
+            "searched_scenes": searched,
+            "ticks_per_s_searched": searched * args.steps / dt,
+            "kernel_ms_avg": {k: (v[0] / max(v[1], 1)) for k, v in kms.items() if v[1] > 0},
             # algorithmic bytes of each kernel over its own average launch time; the kernels of neighbouring
             # ticks overlap on three streams, so these are per-kernel rates, not shares of the tick
             "kernel_algorithmic_GBps": {k: (per_kernel[k] * n / (v[0] / max(v[1], 1) * 1e-3) / 1e9 if v[0] > 0 else 0.0)
-                                        for k, v in kms.items() if k in per_kernel},
+                                        for k, v in kms.items() if k in per_kernel and v[1] > 0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": per_kernel[dom] * n, "avg_launch_ms": avg_ms,
-                         "note": "algorithmic bytes per SURVEY 8(d): one byte per grid cell + the path; the kernel reads the grid bit-packed, see traffic"},
+                         "note": "algorithmic bytes per SURVEY 8(d): one byte per grid cell + the path; the kernel reads the grid bit-packed, see traffic"
+                                 + ("; rank 0's kernel, every rank's own figure under multi_gpu.per_rank" if multi else "")},
             "cpu_baseline": cpu,
         }
+        if multi:
+            line["multi_gpu"] = multi
         print(json.dumps(line))
     pl.close()
     if dist is not None:

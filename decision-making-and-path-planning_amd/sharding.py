@@ -2,9 +2,12 @@
 statics are per-scene state, so the only exchange is a scatter of inputs from rank 0
 and a gather of results — torch.distributed over RCCL/xGMI on GPUs (backend "nccl"), gloo on CPU.
 No collective sits on the data path of a tick."""
+import time
+
 import numpy as np
 
 KEYS = ("scene_in", "lane_pool", "attr_pool", "ref_pool", "obs_pool", "mot_pool", "state")
+RESULT_KEYS = ("plan", "state", "grid_out")
 
 
 def shard_nbytes(dm, n_scenes, n_obs):
@@ -20,21 +23,53 @@ def shard_nbytes(dm, n_scenes, n_obs):
     }
 
 
-def scatter_scenes(dm, dist, torch, cfg, n_scenes, n_obs, rank, world, device, junction_every=8):
-    """Rank 0 generates every rank's shard (offsets are shard-local) and scatters it; returns this
-    rank's buffers as uint8 tensors on `device`."""
-    sizes = shard_nbytes(dm, n_scenes, n_obs)
-    shards = None
-    if rank == 0:
-        shards = [dm.gen_scenes(cfg, r * n_scenes, n_scenes, n_obs, junction_every) for r in range(world)]
-    out = {}
+def _layout(sizes):
+    """Offsets of the buffers inside one packed shard (256-byte aligned: the views are handed to the device as pointers)."""
+    off, o = {}, 0
     for k in KEYS:
-        dst = torch.empty(sizes[k], dtype=torch.uint8, device=device)
-        src = None
-        if rank == 0:
-            src = [torch.from_numpy(np.frombuffer(s[k].tobytes(), np.uint8).copy()).to(device) for s in shards]
-        dist.scatter(dst, src, src=0)
-        out[k] = dst
+        off[k] = o
+        o += (sizes[k] + 255) // 256 * 256
+    return off, o
+
+
+def scatter_scenes(dm, dist, torch, cfg, n_scenes, n_obs, rank, world, device, junction_every=8, timed=False):
+    """Rank 0 generates every rank's shard (offsets are shard-local), packs each into ONE byte buffer and scatters them
+    with one collective (rank 0 -> rank k directly: one xGMI link each, all at once); returns this rank's buffers as
+    uint8 views of the received shard on `device` (and the milliseconds the collective took when `timed`)."""
+    sizes = shard_nbytes(dm, n_scenes, n_obs)
+    off, total = _layout(sizes)
+    src = None
+    if rank == 0:
+        src = []
+        for r in range(world):
+            s = dm.gen_scenes(cfg, r * n_scenes, n_scenes, n_obs, junction_every)
+            buf = np.zeros(total, np.uint8)
+            for k in KEYS:
+                buf[off[k]:off[k] + sizes[k]] = np.frombuffer(s[k].tobytes(), np.uint8)
+            src.append(torch.from_numpy(buf).to(device))
+    dst = torch.empty(total, dtype=torch.uint8, device=device)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dist.scatter(dst, src, src=0)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    out = {k: dst[off[k]:off[k] + sizes[k]] for k in KEYS}
+    return (out, ms) if timed else out
+
+
+def result_tensors(dm, torch, pl, n_scenes, device):
+    """PlanOut, SceneState and GridOut of the handle's resident scenes as uint8 tensors on `device`.  For a GPU
+    `device` the library copies device-to-device straight into the tensors (pp_get_* take host or device pointers),
+    so the RCCL gather needs no host hop."""
+    dts = {"plan": dm.PlanOut, "state": dm.SceneState, "grid_out": dm.GridOut}
+    getters = {"plan": pl.lib.pp_get_plan, "state": pl.lib.pp_get_state, "grid_out": pl.lib.pp_get_grid_out}
+    out = {}
+    for k in RESULT_KEYS:
+        t = torch.empty(n_scenes * dts[k].itemsize, dtype=torch.uint8, device=device)
+        dm._check(getters[k](pl.h, t.data_ptr(), n_scenes))
+        out[k] = t
     return out
 
 

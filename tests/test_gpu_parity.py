@@ -5,6 +5,8 @@ cause, occupancy grid, node-expansion order, digest, counters, chosen path; floa
 relative.  PARITY UNPINNED versus the reference itself: it ships no tests or golden vectors and
 cannot be built here (see oracle/dmpp_oracle.h); the oracle is a line-cited restatement.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -609,29 +611,48 @@ def test_bench_workloads_full_size(dm, oracle, grid, n_obs, dynamic, n_ticks):
             assert (pl.get_path(s, int(go["path_len"])) == path_o).all(), s
 
 
-def test_bench_two_ranks_rehearsal(dm, oracle):
-    """bench.py's N > 1 code path (scatter from rank 0, device pointers into pp_set_scenes, max-over-ranks timing,
-    gather) with two ranks sharing this box's GPU over gloo; the measured runs use RCCL with one rank per GPU."""
+def test_bench_two_ranks_rehearsal(dm, oracle, tmp_path):
+    """`python bench.py --gpus 2` - plain python, no torchrun: the bench starts its own ranks - at the per-rank workload of
+    BASELINE configs[2] (1024 scenes, 512 x 512, 64 obstacles).  The N > 1 code path (scatter from rank 0, device pointers
+    into pp_set_scenes, max-over-ranks timing, gather of PlanOut + SceneState + GridOut, bit-for-bit check of every shard
+    on rank 0) runs with two ranks sharing this box's GPU over gloo; the measured runs use RCCL with one rank per GPU.
+    Both gathered shards are then compared with the oracle."""
     import json
-    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--scenes", "96", "--grid", "128", "--obstacles", "16", "--backend", "gloo", "--no-cpu-baseline", "--latency-ticks", "0"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
-    print(r.stdout[-2000:], r.stderr[-1500:])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    dump = str(tmp_path / "gathered.npz")
+    n, grid, n_obs, warm, steps = 1024, 512, 64, 1, 2
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
+           "--scenes", str(n), "--grid", str(grid), "--obstacles", str(n_obs), "--backend", "gloo", "--no-cpu-baseline",
+           "--latency-ticks", "0", "--dump-gathered", dump]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    print(r.stdout[-3000:], r.stderr[-1500:])
     assert r.returncode == 0
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["global_scenes"] == 192 and line["value"] > 0
-    cfg = dm.default_config(128)                          # rank 0's shard is seeds 0..95: same statuses as the oracle's
-    sc = dm.gen_scenes(cfg, 0, 96, 16, junction_every=8)
-    st = sc["state"].copy()
-    for _ in range(4):
-        _, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st, n_threads=8, want_grid=True)
-    assert line["search_status_counts"] == np.bincount(gout_o["status"], minlength=6).tolist()
+    assert line["n_gpus"] == 2 and line["config"]["global_scenes"] == 2 * n and line["value"] > 0
+    mg = line["multi_gpu"]
+    per_scene = dm.PlanOut.itemsize + dm.SceneState.itemsize + dm.GridOut.itemsize
+    assert mg["gathered_bytes"] == 2 * n * per_scene
+    assert mg["shards_verified"] == 2 and mg["shard_mismatches"] == 0
+    assert [p["rank"] for p in mg["per_rank"]] == [0, 1]
+    assert all(p["frac"] > 0 and p["avg_launch_ms"] > 0 for p in mg["per_rank"])
+    got = np.load(dump)
+    cfg = dm.default_config(grid)
+    threads = min(64, os.cpu_count() or 8)
+    counts = np.zeros(6, np.int64)
+    for rk in range(2):                                    # rank rk's shard is scenes rk*n .. rk*n + n - 1
+        sc = dm.gen_scenes(cfg, rk * n, n, n_obs, junction_every=8)
+        st = sc["state"].copy()
+        plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st, n_threads=threads, want_grid=True, n_ticks=warm + steps)
+        sl = slice(rk * n, (rk + 1) * n)
+        bad = (compare(got["plan"][sl], plan_o, "plan") + compare(got["state"][sl], st, "state")
+               + compare(got["grid_out"][sl], gout_o, "grid"))
+        assert not bad, f"rank {rk}:\n" + "\n".join(bad[:10])
+        counts += np.bincount(gout_o["status"], minlength=6)
+    assert line["search_status_counts"] == counts.tolist()
+    assert line["searched_scenes"] == int(counts.sum() - counts[dm.G_GOAL_BLOCKED])
 
 
 @pytest.mark.parametrize("dx,dy", [(25.0, 0.0), (-30.0, 0.0), (0.0, -40.0)])

@@ -40,11 +40,14 @@ def _worker(rank, world, port, n, n_obs, q):
     orc = oracle_binding.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
     st = sc["state"].copy()
     plan, gout, _ = orc.plan_tick_batch(cfg, sc, st)
-    mine = torch.from_numpy(gout["order_digest"].astype(np.int64))
-    allg = sharding.gather_results(dist, torch, mine, rank, world)
+    # the gather of SURVEY 8(e): PlanOut + SceneState + GridOut of every scene, as bytes
+    allg = {}
+    for k, a in (("plan", plan), ("state", st), ("grid_out", gout)):
+        mine = torch.from_numpy(np.frombuffer(a.tobytes(), np.uint8).copy())
+        allg[k] = sharding.gather_results(dist, torch, mine, rank, world)
     dist.barrier()
     if rank == 0:
-        q.put((same, [t.numpy().copy() for t in allg]))
+        q.put((same, {k: [t.numpy().copy() for t in v] for k, v in allg.items()}))
     else:
         q.put((same, None))
     dist.destroy_process_group()
@@ -68,6 +71,27 @@ def test_scatter_tick_gather_world2(dm, oracle):
     cfg = dm.default_config(128)
     whole = dm.gen_scenes(cfg, 0, n * world, n_obs, 8)          # the same scenes in one process
     st = whole["state"].copy()
-    _, gout, _ = oracle.plan_tick_batch(cfg, whole, st)
-    want = gout["order_digest"].astype(np.int64)
-    assert np.array_equal(np.concatenate(gathered), want)
+    plan, gout, _ = oracle.plan_tick_batch(cfg, whole, st)
+    from parity_util import compare
+    for k, want in (("plan", plan), ("state", st), ("grid_out", gout)):
+        got = np.frombuffer(np.concatenate(gathered[k]).tobytes(), want.dtype)
+        assert len(got) == n * world
+        bad = compare(got, want, k, rtol=0.0, atol=0.0)
+        assert not bad, bad[:5]
+
+
+def test_bench_spawns_its_own_ranks_and_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) starts two ranks itself; on a box without GPUs every rank
+    refuses to run (no CPU fallback) and the parent reports the exit codes and exits non-zero."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--scenes", "4", "--grid", "128", "--obstacles", "4", "--no-cpu-baseline", "--latency-ticks", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU: the spawn path is covered by the -m gpu rehearsal")
+    assert r.returncode != 0
+    assert r.stderr.count("needs a GPU") == 2, r.stderr[-2000:]
+    assert "rank exit codes" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

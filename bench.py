@@ -210,7 +210,7 @@ def main():
         stats = [None] * world
         dist.all_gather_object(stats, {"rank": rank, "ms_per_step": dt_local / args.steps * 1e3, "kernel": dom, "avg_launch_ms": avg_ms,
                                        "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS,
-                                       "search_status_counts": np.bincount(gout["status"], minlength=6).tolist()})
+                                       "search_status_counts": np.bincount(gout["status"], minlength=dm.G_STATUS_COUNT).tolist()})
         if rank == 0:
             dts = {"plan": dm.PlanOut, "state": dm.SceneState, "grid_out": dm.GridOut}
             gathered = {k: [np.frombuffer(t.cpu().numpy().tobytes(), dts[k]) for t in allg[k]] for k in dts}
@@ -370,7 +370,7 @@ def main():
                 for name, k in pmc.items():
                     if name.split("<")[0] == dom and "hbm_bytes_gfx950_corrected" in k:
                         traffic, traffic_src = k["hbm_bytes_gfx950_corrected"], "profiles/%s_pmc.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)" % cand
-        status_counts = np.bincount(gout["status"], minlength=6)
+        status_counts = np.bincount(gout["status"], minlength=dm.G_STATUS_COUNT)
         if multi:
             status_counts = np.sum([s["search_status_counts"] for s in multi["per_rank"]], axis=0)
         searched = int(status_counts.sum() - status_counts[dm.G_GOAL_BLOCKED])

@@ -18,10 +18,11 @@ LIB_PATH = os.path.join(_HERE, "libdmpp.so")
 PATH_POINTS, OUT_POINTS, LANESUM, MAX_REFPATH, MAX_LATTICE = 200, 100, 8, 512, 17
 GEN_LANE_PTS, GEN_REF_PTS = 320, 128
 
-G_FOUND, G_NO_PATH, G_LIMIT, G_OVERFLOW, G_GOAL_BLOCKED, G_PATH_TRUNC = range(6)
+G_FOUND, G_NO_PATH, G_LIMIT, G_OVERFLOW, G_GOAL_BLOCKED, G_PATH_TRUNC, G_INTERNAL, G_COST_RANGE = range(8)
+G_STATUS_COUNT = 8
 K_NAMES = ["k_effective_obstacles", "k_decision", "k_planning", "k_rasterise", "k_search", "k_score"]
 (BUF_SCENE_IN, BUF_LANE_POOL, BUF_REF_POOL, BUF_OBS_POOL, BUF_MOT_POOL, BUF_STATE, BUF_PLAN_OUT, BUF_GRID_OUT,
- BUF_GRID, BUF_PATH, BUF_ORDER) = range(11)
+ BUF_GRID, BUF_PATH, BUF_ORDER, BUF_LANE_ATTR) = range(12)
 
 
 def _dt(fields):
@@ -129,7 +130,8 @@ def load_library(path=None):
     lib.pp_destroy.argtypes = [vp]
     lib.pp_set_config.argtypes = [vp, vp]
     lib.pp_set_scenes.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, vp, ci]
-    lib.pp_set_n_scenes.argtypes = [vp, ci]
+    lib.pp_set_n_scenes.argtypes = [vp, ci, ci, ci, ci, ci, ci]
+    lib.pp_join.argtypes = [vp]
     lib.pp_set_map.argtypes = [vp, vp]
     lib.pp_set_egos.argtypes = [vp, ci, vp, vp, vp, ci]
     lib.pp_get_scene_in.argtypes = [vp, vp, ci]
@@ -278,6 +280,10 @@ class Planner:
 
     def sync(self):
         _check(self.lib.pp_sync(self.h))
+
+    def join(self):
+        """pp_join: the handle's stream waits (on the device) for every tick enqueued so far."""
+        _check(self.lib.pp_join(self.h))
 
     def get_plan(self):
         out = np.zeros(self.n, PlanOut)

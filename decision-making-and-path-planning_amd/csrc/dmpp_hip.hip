@@ -1,7 +1,10 @@
 // dmpp_hip.hip — the C-ABI of include/dmpp_planner.h over the HIP kernels (gfx950 only).
 //
-// One handle = one device, one stream, all device buffers.  pp_plan_tick enqueues, in order:
-//   k_effective_obstacles -> k_decision -> k_planning -> k_rasterise -> k_search -> k_score
+// One handle = one device, all device buffers, four streams: the handle's stream (the search chain, high priority; also
+// every copy and stand-alone operator), a second search stream for overlapping searches of odd ticks, and two CU-masked
+// side streams (FRONT: obstacle snapshot, rasterise, Decision, Planning; SCORE: k_score).  pp_plan_tick describes the
+// launch order and the events between the chains; batches below pipeline_min scenes run on the handle's stream with only
+// Decision + Planning forked beside the grid engine.  Every host-visible call joins the chains first (join_all).
 // Nothing here computes planning results on the host; without a GPU pp_create fails.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -60,6 +63,10 @@ struct pp_planner {
     hipEvent_t ev_raster = nullptr;
     bool score_recorded[2] = { false, false }, search_recorded[2] = { false, false }, front_recorded = false, front_unjoined = false;
     int parity = 0;              // buffers of the last tick
+    int pipeline_min = 256;      // batches at least this large run the three chains on three streams (env DMPP_PIPELINE_MIN)
+    bool r_on_main = false;      // the last tick ran Decision + Planning on the handle's stream (grid stage off)
+    int n_lane_pts = 0, n_ref_pts = 0;   // pool sizes of the resident scenes (slice validation)
+    int* d_bad = nullptr;        // k_validate_scenes: scenes with a slice outside its pool
     // map store (pp_set_map): lane / junction tables; the point pools are d_lane / d_attr / d_ref
     int32_t* d_map_first = nullptr; MapLane* d_map_lanes = nullptr; uint16_t* d_map_width = nullptr; MapJunction* d_map_junc = nullptr;
     int* d_map_bad = nullptr; int map_roads = 0, map_lanes = 0, map_junctions = 0; bool have_map = false;
@@ -105,10 +112,11 @@ hipEvent_t get_event(pp_planner* h)
 
 constexpr int kScoreWideMaxScenes = 128;     // up to here k_score runs 16 waves per scene (one scene per CU at most)
 constexpr int kSearchSlots = 512;            // search waves resident at once on 256 CUs (80 KB of LDS each)
-int kPipelineMinScenes = 256;                // batches at least this large run the three chains on three streams (env DMPP_PIPELINE_MIN)
 
-// Everything a tick started is ordered before whatever the handle's stream does next.
-int join_score(pp_planner* h)
+// Everything the ticks enqueued so far started - on any of the four streams - is ordered before whatever the handle's
+// stream does next: ev_score[q] closes the raster -> search -> score chain of the last tick of parity q, ev_join the
+// Decision -> Planning chain (stream order covers the earlier ticks).  No host wait.
+int join_all(pp_planner* h)
 {
     for (int q = 0; q < 2; q++) if (h->score_recorded[q]) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_score[q], 0));
     if (h->front_recorded) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -128,7 +136,7 @@ struct Timed {
 int drain_events(pp_planner* h)
 {
     if (h->pending.empty()) return PP_OK;
-    { int r = join_score(h); if (r) return r; }
+    { int r = join_all(h); if (r) return r; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (auto& p : h->pending) {
         float ms = 0;
@@ -217,7 +225,6 @@ const char* pp_last_error(void) { return g_err.c_str(); }
 int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_handle* out)
 {
     if (!out || !caps) return fail(PP_ERR_ARG, "null argument");
-    if (const char* e = std::getenv("DMPP_PIPELINE_MIN")) kPipelineMinScenes = std::atoi(e);      // tuning knob: 0 = always, large = never
     *out = nullptr;
     int r = check_cfg(cfg); if (r) return r;
     if (caps->max_scenes <= 0) return fail(PP_ERR_ARG, "max_scenes must be positive");
@@ -229,6 +236,7 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     pp_planner* h = new (std::nothrow) pp_planner();
     if (!h) return fail(PP_ERR_HIP, "out of host memory");
     h->cfg = *cfg; h->caps = *caps; h->device = device;
+    if (const char* e = std::getenv("DMPP_PIPELINE_MIN")) h->pipeline_min = std::atoi(e);      // tuning knob: 0 = always, large = never
     auto bail = [&](int code) { pp_destroy(h); return code; };
     // the search chain gets the highest dispatch priority, the chains that run beside it the lowest: a waiting search
     // workgroup (80 KB of LDS) must not queue behind the short kernels that fill the gaps
@@ -271,6 +279,9 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     if ((r = dmalloc(&h->d_ref, (size_t)caps->max_ref_pts_total))) return bail(r);
     if ((r = dmalloc(&h->d_obs, (size_t)caps->max_obs_total))) return bail(r);
     if ((r = dmalloc(&h->d_mot, (size_t)caps->max_obs_total))) return bail(r);
+    if (hipMemsetAsync(h->d_mot, 0, (size_t)(caps->max_obs_total > 0 ? caps->max_obs_total : 1) * sizeof(ObMotion), h->stream) != hipSuccess)
+        return bail(fail(PP_ERR_HIP, "memset failed"));     // velocities nobody uploaded are zero, never uninitialised
+    if ((r = dmalloc(&h->d_bad, (size_t)1))) return bail(r);
     for (int q = 0; q < 2; q++) if ((r = dmalloc(&h->d_obs_now[q], (size_t)caps->max_obs_total))) return bail(r);
     if ((r = dmalloc(&h->d_state, ns))) return bail(r);
     if ((r = dmalloc(&h->d_plan, ns))) return bail(r);
@@ -308,7 +319,7 @@ int pp_destroy(pp_handle h)
     void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now[0], h->d_obs_now[1], h->d_state, h->d_plan,
                      h->d_gout[0], h->d_gout[1], h->d_dec_ref, h->d_grid, h->d_pinfo[0], h->d_pinfo[1], h->d_closed[0], h->d_closed[1],
                      h->d_order[0], h->d_order[1], h->d_path[0], h->d_path[1], h->d_gbm[0], h->d_gbm[1], h->d_perm[0], h->d_perm[1],
-                     h->d_cost[0], h->d_cost[1], h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad };
+                     h->d_cost[0], h->d_cost[1], h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad, h->d_bad };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int q = 0; q < 2; q++) { if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]); if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]); }
     if (h->ev_raster) (void)hipEventDestroy(h->ev_raster);
@@ -332,8 +343,30 @@ int pp_set_config(pp_handle h, const PlannerConfig* cfg)
             return fail(PP_ERR_CAPACITY, "grid size / bucket_cap / max_path may not grow after pp_create");
     }
     HIP_TRY(hipSetDevice(h->device));
+    // a configuration change may move the next tick's kernels to other streams (grid stage on / off): finish what is queued
+    { int r = join_all(h); if (r) return r; }
+    HIP_TRY(hipStreamSynchronize(h->stream));
     h->cfg = *cfg;
     return setup_grid_launch(h);
+}
+
+// Slices of the resident SceneIn records against the resident pools (k_validate_scenes); syncs the handle's stream.
+static int validate_resident(pp_handle h, int n_scenes, const char* who)
+{
+    int bad = 0;
+    if (n_scenes > 0) {
+        HIP_TRY(hipMemsetAsync(h->d_bad, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(dmpp::k_validate_scenes, dim3((unsigned)((n_scenes + dmpp::kBlock - 1) / dmpp::kBlock)), dim3(dmpp::kBlock), 0, h->stream,
+                           n_scenes, h->d_in, h->n_obs_total, h->n_lane_pts, h->n_ref_pts, h->d_bad);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&bad, h->d_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (bad) {
+        h->n_scenes = 0;                                // nothing a tick could follow out of its pool stays resident
+        return fail(PP_ERR_ARG, std::string(who) + ": " + std::to_string(bad) + " scene(s) with an obstacle / lane / refpath slice outside its pool");
+    }
+    return PP_OK;
 }
 
 int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoint3D* lane_pool, const uint8_t* lane_attr_pool,
@@ -345,7 +378,7 @@ int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoin
         return fail(PP_ERR_CAPACITY, "pool larger than the capacity given to pp_create");
     if (n_lane_pts < 0 || n_ref_pts < 0 || n_obs_total < 0) return fail(PP_ERR_ARG, "negative size");
     HIP_TRY(hipSetDevice(h->device));
-    { int r = join_score(h); if (r) return r; }
+    { int r = join_all(h); if (r) return r; }
     HIP_TRY(hipMemcpyAsync(h->d_in, in, (size_t)n_scenes * sizeof(SceneIn), hipMemcpyDefault, h->stream));
     if (n_lane_pts && lane_pool) HIP_TRY(hipMemcpyAsync(h->d_lane, lane_pool, (size_t)n_lane_pts * sizeof(GlobalPoint3D), hipMemcpyDefault, h->stream));
     h->have_attr = false;
@@ -360,9 +393,8 @@ int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoin
         HIP_TRY(hipMemcpyAsync(h->d_mot, mot_pool, (size_t)n_obs_total * sizeof(ObMotion), hipMemcpyDefault, h->stream));
         h->have_motion = true;
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));     // the caller may reuse its buffers
-    h->n_scenes = n_scenes; h->n_obs_total = n_obs_total;
-    return PP_OK;
+    h->n_scenes = n_scenes; h->n_obs_total = n_obs_total; h->n_lane_pts = n_lane_pts; h->n_ref_pts = n_ref_pts;
+    return validate_resident(h, n_scenes, "pp_set_scenes");     // syncs: the caller may reuse its buffers
 }
 
 static int fetch(pp_handle h, void* dst, const void* src, size_t bytes);
@@ -387,7 +419,7 @@ int pp_set_map(pp_handle h, const MapDesc* m)
         if (J.point_off < 0 || J.n_points < 0 || (long long)J.point_off + J.n_points > m->n_jpoints) return fail(PP_ERR_ARG, "junction slice outside the junction point pool");
     }
     HIP_TRY(hipSetDevice(h->device));
-    { int r = join_score(h); if (r) return r; }
+    { int r = join_all(h); if (r) return r; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     void* old[] = { h->d_map_first, h->d_map_lanes, h->d_map_junc };
     for (void* b : old) if (b) (void)hipFree(b);
@@ -410,6 +442,7 @@ int pp_set_map(pp_handle h, const MapDesc* m)
     if (m->n_jpoints) HIP_TRY(hipMemcpyAsync(h->d_ref, m->jpoints, (size_t)m->n_jpoints * sizeof(GlobalPoint2D), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->map_roads = m->n_roads; h->map_lanes = m->n_lanes; h->map_junctions = m->n_junctions;
+    h->n_lane_pts = m->n_points; h->n_ref_pts = m->n_jpoints;
     h->have_map = true; h->have_attr = true;
     return PP_OK;
 }
@@ -421,7 +454,7 @@ int pp_set_egos(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs
     if (n_scenes < 0 || n_scenes > h->caps.max_scenes) return fail(PP_ERR_CAPACITY, "n_scenes exceeds caps.max_scenes");
     if (n_obs_total < 0 || n_obs_total > h->caps.max_obs_total) return fail(PP_ERR_CAPACITY, "obstacle pool larger than caps.max_obs_total");
     HIP_TRY(hipSetDevice(h->device));
-    { int r = join_score(h); if (r) return r; }
+    { int r = join_all(h); if (r) return r; }
     HIP_TRY(hipMemcpyAsync(h->d_in, in, (size_t)n_scenes * sizeof(SceneIn), hipMemcpyDefault, h->stream));
     if (n_obs_total && obs_pool) HIP_TRY(hipMemcpyAsync(h->d_obs, obs_pool, (size_t)n_obs_total * sizeof(ObPoint), hipMemcpyDefault, h->stream));
     h->have_motion = false;
@@ -439,8 +472,8 @@ int pp_set_egos(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs
     HIP_TRY(hipMemcpyAsync(&bad, h->d_map_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->n_scenes = n_scenes; h->n_obs_total = n_obs_total;
-    if (bad) return fail(PP_ERR_ARG, "pp_set_egos: " + std::to_string(bad) + " scene(s) name a road or lane outside the map");
-    return PP_OK;
+    if (bad) { h->n_scenes = 0; return fail(PP_ERR_ARG, "pp_set_egos: " + std::to_string(bad) + " scene(s) name a road or lane outside the map"); }
+    return validate_resident(h, n_scenes, "pp_set_egos");       // the obstacle slices are still the caller's
 }
 
 int pp_get_scene_in(pp_handle h, SceneIn* out, int n)
@@ -450,12 +483,18 @@ int pp_get_scene_in(pp_handle h, SceneIn* out, int n)
     return fetch(h, out, h->d_in, (size_t)n * sizeof(SceneIn));
 }
 
-int pp_set_n_scenes(pp_handle h, int n_scenes)
+int pp_set_n_scenes(pp_handle h, int n_scenes, int n_lane_pts, int n_ref_pts, int n_obs_total, int have_motion, int have_lane_attr)
 {
     if (!h) return fail(PP_ERR_ARG, "null handle");
     if (n_scenes < 0 || n_scenes > h->caps.max_scenes) return fail(PP_ERR_CAPACITY, "n_scenes exceeds caps.max_scenes");
-    h->n_scenes = n_scenes; h->have_motion = true;
-    return PP_OK;
+    if (n_lane_pts < 0 || n_ref_pts < 0 || n_obs_total < 0) return fail(PP_ERR_ARG, "negative size");
+    if (n_lane_pts > h->caps.max_lane_pts_total || n_ref_pts > h->caps.max_ref_pts_total || n_obs_total > h->caps.max_obs_total)
+        return fail(PP_ERR_CAPACITY, "pool larger than the capacity given to pp_create");
+    HIP_TRY(hipSetDevice(h->device));
+    { int r = join_all(h); if (r) return r; }
+    h->n_scenes = n_scenes; h->n_obs_total = n_obs_total; h->n_lane_pts = n_lane_pts; h->n_ref_pts = n_ref_pts;
+    h->have_motion = have_motion != 0; h->have_attr = have_lane_attr != 0;
+    return validate_resident(h, n_scenes, "pp_set_n_scenes");
 }
 
 int pp_set_state(pp_handle h, const SceneState* state, int n)
@@ -463,7 +502,7 @@ int pp_set_state(pp_handle h, const SceneState* state, int n)
     if (!h || !state) return fail(PP_ERR_ARG, "null argument");
     if (n < 0 || n > h->caps.max_scenes) return fail(PP_ERR_CAPACITY, "n exceeds caps.max_scenes");
     HIP_TRY(hipSetDevice(h->device));
-    { int r = join_score(h); if (r) return r; }
+    { int r = join_all(h); if (r) return r; }
     HIP_TRY(hipMemcpyAsync(h->d_state, state, (size_t)n * sizeof(SceneState), hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PP_OK;
@@ -487,7 +526,7 @@ int pp_plan_tick(pp_handle h)
     // Small batches and ticks without the grid stage stay on one stream (a cross-stream hand-over costs tens of
     // microseconds; only Decision + Planning run beside the grid engine there).
     const int p = h->parity ^ 1;
-    const bool piped = c.grid_stage && n >= kPipelineMinScenes;
+    const bool piped = c.grid_stage && n >= h->pipeline_min;
     // consecutive searches overlap when a search is long next to the front chain (Decision, Planning and the rasteriser share
     // one stream and bound the tick from below): many obstacles per scene, or grids beyond 512 x 512.  Measured: 256 obstacles
     // +40 %, 2048 x 2048 +7 %, but -8 % on 64 obstacles at 512 x 512, where the front chain is as long as the search.
@@ -502,6 +541,10 @@ int pp_plan_tick(pp_handle h)
     if (!overlap && h->search_recorded[p ^ 1]) HIP_TRY(hipStreamWaitEvent(sm, h->ev_search[p ^ 1], 0));   // one search at a time (also after a switch of mode)
     if (h->front_recorded && sf == h->stream && h->front_unjoined) HIP_TRY(hipStreamWaitEvent(sf, h->ev_join, 0));   // Planning(t-1) -> snapshot(t) when not on the same stream
     h->front_unjoined = false;
+    if (h->r_on_main && sf != h->stream) {         // Planning(t-1) ran on the handle's stream (grid stage off then): the front chain reads its state
+        HIP_TRY(hipEventRecord(h->ev_fork, h->stream)); HIP_TRY(hipStreamWaitEvent(sf, h->ev_fork, 0));
+    }
+    h->r_on_main = sr == h->stream;
     ObPoint* obs_now = h->d_obs_now[p];
     {
         Timed t(h, PP_K_OBSTACLES, sf);
@@ -571,11 +614,18 @@ int pp_plan_tick(pp_handle h)
     return PP_OK;
 }
 
+int pp_join(pp_handle h)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return join_all(h);
+}
+
 int pp_sync(pp_handle h)
 {
     if (!h) return fail(PP_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    { int r = join_score(h); if (r) return r; }
+    { int r = join_all(h); if (r) return r; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PP_OK;
 }
@@ -583,7 +633,7 @@ int pp_sync(pp_handle h)
 static int fetch(pp_handle h, void* dst, const void* src, size_t bytes)
 {
     HIP_TRY(hipSetDevice(h->device));
-    { int r = join_score(h); if (r) return r; }
+    { int r = join_all(h); if (r) return r; }
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PP_OK;
@@ -614,6 +664,7 @@ int pp_get_grid(pp_handle h, int scene, uint8_t* grid)
     const size_t N = (size_t)h->cfg.grid_w * h->cfg.grid_h;
     // the tick keeps the grid bit-packed; its byte form is produced here, for the one scene asked for
     HIP_TRY(hipSetDevice(h->device));
+    { int r = join_all(h); if (r) return r; }       // the rasteriser of the last tick ran on another stream
     hipLaunchKernelGGL(dmpp::k_expand_grid, dim3((unsigned)((N / 16 + dmpp::kRasterBlock - 1) / dmpp::kRasterBlock)), dim3(dmpp::kRasterBlock), 0,
                        h->stream, h->cfg.grid_w, h->cfg.grid_h, h->d_gbm[h->parity] + (size_t)scene * 2 * (N / 32), h->d_grid);
     HIP_TRY(hipGetLastError());

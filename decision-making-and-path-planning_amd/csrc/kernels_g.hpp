@@ -1,16 +1,17 @@
 // kernels_g.hpp — HIP kernels of the grid engine (specification in
 // DESIGN.md §5 and oracle/dmpp_grid_oracle.c — the reference has no grid code).
 //
-//   k_rasterise : obstacle list -> u8 occupancy grid in HBM.  One workgroup per (scene, band of
-//                 rows): footprints are OR-ed into an LDS bit band, then the band is expanded to
-//                 bytes and written with 16-B-per-lane coalesced stores (HBM-write bound).
-//   k_search    : jump-point A*.  ONE WAVE per scene: the u8 grid is read once with 16-B-per-lane
-//                 coalesced loads into LDS obstacle bitmaps (row- and column-major); straight jumps
-//                 are lane-parallel bit scans (32 cells per lane, ballot + ffs), several per pass;
-//                 the open list and the closed-set hash are LDS resident (DPP minimum, ballot +
-//                 prefix-popcount compaction); up to 4 nodes of the minimal f are expanded per step.
+//   k_rasterise : obstacle list -> bit-packed occupancy grid in HBM, row-major and column-major.  One workgroup
+//                 per (scene, band of rows): footprints are OR-ed into two LDS bit bands (the same cell in both
+//                 orientations), then the bands are written out word by word (HBM-write bound; 1/8 of a byte grid).
+//   k_expand_grid: one scene's bitmap -> u8 grid, on demand (pp_get_grid).
+//   k_order     : launch order of the search, heaviest scenes first (counting sort on the previous search times).
+//   k_search    : jump-point A*.  Four waves set a scene up (bitmaps HBM -> LDS by LDS-DMA, word summaries, empty
+//                 closed set), then ONE wave searches: a straight jump is one lane walking the candidate words of its
+//                 line; a diagonal jump is a group of 16 lanes; the open list and the closed-set hash are LDS resident
+//                 (DPP minimum, ballot + prefix-popcount compaction); up to 4 nodes of the minimal f per step.
 //   k_score     : lattice candidates (cubic Beziers to laterally shifted terminals + the grid
-//                 path) scored on collision / curvature / progress, 4 waves per scene.
+//                 path) scored on collision / curvature / progress, 4 (or 16) waves per scene.
 #pragma once
 #include "dev_geom.hpp"
 
@@ -33,8 +34,8 @@ __device__ __forceinline__ int cell_of(const PlannerConfig& c, GlobalPoint2D ori
 }
 
 // ---------------------------------------------------------------------------------------
-// G1.  grid: [n_scenes][H][W] u8, 0 free / 1 occupied (the host guarantees W % 32 == 0, so a band of
-// whole rows is a whole number of 32-bit words and of 16-byte stores).
+// G1.  grid: per scene H x W/32 words row-major, then W x H/32 words column-major; bit = 1 occupied (the host
+// guarantees W % 32 == 0 and H % 32 == 0, and bands of a multiple of 32 rows: whole words in both orientations).
 constexpr int kRasterBlock = 256;
 
 __global__ void __launch_bounds__(kRasterBlock)
@@ -134,20 +135,19 @@ __device__ __forceinline__ int hfun(int x, int y, int gx, int gy)
     return 10 * max(dx, dy) + 4 * min(dx, dy);
 }
 
-// G2: jump-point A* (specification: oracle/dmpp_grid_oracle.c).  ONE WAVE per scene.
-//   * the u8 grid is read once (16 B per lane, coalesced), packed to an LDS bitmap of obstacles and
-//     transposed in registers into a column-major copy: E/W and N/S jumps are both line scans;
-//   * a straight jump is a JOB of jw lanes (16 / 32 / 64 by grid width): every lane takes a 32-cell word
-//     of the line and builds the stop mask  blocked | forced | goal  from the three neighbouring lines
-//     with two shifts; ballot + ffs find the first stop.  All jumps of a step (<= 8) share passes;
-//   * a step takes up to 4 open entries of the minimal f (their g is final, so the search stays
-//     optimal), closes them and expands them on 4 x 8 lanes (node x direction); diagonal moves are
-//     single steps that go through the open list;
+// G2: jump-point A* (specification: oracle/dmpp_grid_oracle.c).  ONE searching wave per scene.
+//   * the bit-packed grid of k_rasterise arrives in LDS by LDS-DMA, both orientations: E/W and N/S jumps are both scans
+//     along a line of words; per line a summary word says which of its words are non-zero;
+//   * a straight jump is ONE lane (jump_lane): it visits, in travel order, only the words where the line or one of its
+//     two neighbours has an obstacle bit (or the goal) and builds  blocked | forced | goal  with two shifts;
+//   * a diagonal jump (<= DMPP_DIAG_JUMP cells) is a group of 16 lanes: lane pair k scans horizontally | vertically from
+//     cell k+1 of the diagonal; the pair of cell 8 is free for the straight successors, so one round serves a step;
+//   * a step takes up to 4 open entries of the minimal f (their g is final, so the search stays optimal), closes them
+//     and expands them on 4 x 8 lanes (node x direction);
 //   * the open list lives in LDS in push order (f/2, x|y|dir, run): minimum by DPP wave reduction, ties
 //     picked with ballots, dead slots squeezed out with ballot + prefix-popcount compaction;
-//   * closed cells: an LDS hash (atomicCAS insertion) answers while it has room, a bit set in HBM is kept
-//     complete behind it; direction + run length per closed cell go to HBM for the path, which is a
-//     handful of runs rather than hundreds of single cells.
+//   * closed cells: an LDS hash (atomicCAS insertion, direction + run length beside the cell) answers while it has room;
+//     a scene that outgrows it moves to a bit set + direction/run array in HBM (spill), zeroed only then.
 constexpr int kOpenCap = DMPP_OPEN_CAP;
 constexpr int kClosedLog = 10, kClosedTab = 1 << kClosedLog, kClosedMax = 768;      // LDS closed-set hash; beyond kClosedMax the HBM bit set answers
 constexpr int kDiagK = DMPP_DIAG_JUMP;                  // cells a diagonal jump looks ahead
@@ -622,7 +622,17 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
             const unsigned pm = (unsigned)__ballot(push);
             const int cnt = __popc(pm);
             if (cnt) {
-                if (live + cnt > cap) { status = DMPP_G_OVERFLOW; break; }
+                const int nx = nx0 + run * sdx, ny = ny0 + run * sdy;
+                const int fn = gcur + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
+                // f/2 lives in 16 bits (0xFFFF = dead slot): a push at or beyond DMPP_F_LIMIT ends the search.  The oracle tests
+                // each push in turn, the range before the capacity: the earlier of the two failing pushes decides the status.
+                const unsigned rm = (unsigned)__ballot(push && fn >= DMPP_F_LIMIT);
+                if (rm || live + cnt > cap) {
+                    const int k_range = rm ? __popc(pm & ((1u << (__ffs((int)rm) - 1)) - 1u)) : 0x7FFFFFFF;
+                    const int k_cap = live + cnt > cap ? cap - live : 0x7FFFFFFF;
+                    status = k_range <= k_cap ? DMPP_G_COST_RANGE : DMPP_G_OVERFLOW;
+                    break;
+                }
                 if (n_open + cnt > kOpenCap) {
                     // squeeze the dead slots out, keeping the push order (ballot + prefix popcount)
                     int w = 0;
@@ -643,8 +653,6 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict
                     n_open = w;
                 }
                 if (push) {
-                    const int nx = nx0 + run * sdx, ny = ny0 + run * sdy;
-                    const int fn = gcur + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
                     const int slot = n_open + __popc(pm & ((1u << lane) - 1u));
                     o_f2[slot] = (uint16_t)(fn >> 1);
                     o_ent[slot] = (uint32_t)nx | ((uint32_t)ny << 12) | ((uint32_t)s << 24);

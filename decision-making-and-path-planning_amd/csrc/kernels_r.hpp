@@ -203,6 +203,22 @@ k_resolve_map(int n_scenes, SceneIn* __restrict__ in, int n_roads, const int32_t
     si.ref_off = roff; si.ref_n = rn;
 }
 
+// One thread per scene: every slice a tick follows out of a SceneIn record - obstacles, the three lane views, the
+// junction polyline - must lie inside its pool (an empty slice may carry any offset: it is never dereferenced).
+// bad[0] counts the scenes that fail; the host refuses the batch (no tick is launched on it).
+__global__ void __launch_bounds__(kBlock)
+k_validate_scenes(int n_scenes, const SceneIn* __restrict__ in, int n_obs_total, int n_lane_pts, int n_ref_pts, int* __restrict__ bad)
+{
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_scenes) return;
+    const SceneIn& si = in[s];
+    auto inside = [](int off, int n, int pool) { return n == 0 || (n > 0 && off >= 0 && (long long)off + n <= (long long)pool); };
+    const bool ok = inside(si.obs_off, si.obs_n, n_obs_total) && inside(si.lanes.cur_off, si.lanes.cur_n, n_lane_pts) &&
+                    inside(si.lanes.left_off, si.lanes.left_n, n_lane_pts) && inside(si.lanes.right_off, si.lanes.right_n, n_lane_pts) &&
+                    inside(si.ref_off, si.ref_n, n_ref_pts);
+    if (!ok) atomicAdd(bad, 1);
+}
+
 // ---------------------------------------------------------------------------------------
 // Lane-change rule tree of CDecision::BehaviorDecision, Decision.cpp:1017-1772, run by one thread per scene
 // on the corridor distances k_decision has just produced.  `rem` holds the remaining-length tests (see

@@ -7,7 +7,7 @@
  * header is what a binding for that path binds instead: plain pointers
  * and sizes, POD structs from dmpp_types.h, int status codes, no C++ or torch types.
  * Every data pointer may be a host pointer or a HIP device pointer (copies use
- * hipMemcpyDefault).  A handle owns one GPU stream and all device scratch; calls on one
+ * hipMemcpyDefault).  A handle owns its GPU streams and all device scratch; calls on one
  * handle are serialised by the caller (the reference is one thread per module,
  * Planning.cpp:24-39).  All cross-tick state is the caller-visible SceneState.
  *
@@ -75,6 +75,8 @@ int  pp_set_config(pp_handle h, const PlannerConfig* cfg);   /* grid size / caps
  * Replaces the blackboard reads of Planning.cpp:95-112 / Decision.cpp:155-160. */
 /* lane_attr_pool[i] is decision_MapData[..][..][id].lanechg_attribute of lane point i (Decision.cpp:1179,1212):
  * one byte per lane-pool point, same indexing.  Required when cfg.lanechg_stage is 1. */
+/* Every scene's slices (obs_off/obs_n, lanes.*_off/_n, ref_off/ref_n) are checked on the device against the pool
+ * sizes given here; a slice outside its pool is PP_ERR_ARG and leaves no scenes resident (no kernel ever follows it). */
 int  pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in,
                    const GlobalPoint3D* lane_pool, const uint8_t* lane_attr_pool, int n_lane_pts,
                    const GlobalPoint2D* ref_pool, int n_ref_pts,
@@ -96,8 +98,14 @@ int  pp_set_egos(pp_handle h, int n_scenes, const SceneIn* in,
 int  pp_get_scene_in(pp_handle h, SceneIn* out, int n_scenes);
 
 /* One Decision+Planning(+grid) tick for every resident scene: the bodies of
- * Decision.cpp:172-205 and Planning.cpp:114-223.  Asynchronous on the handle's stream. */
+ * Decision.cpp:172-205 and Planning.cpp:114-223.  Asynchronous: the kernels of a tick run on several streams of the
+ * handle (large batches: three chains side by side, consecutive ticks overlapping), so work a caller enqueues on
+ * pp_stream(h) is NOT ordered after a tick by itself.  Every pp_get_* / pp_set_* call orders itself after all ticks
+ * enqueued so far; for anything else on pp_stream(h) (an RCCL gather out of pp_device_ptr buffers) call pp_join first. */
 int  pp_plan_tick(pp_handle h);
+/* Makes pp_stream(h) wait, on the device, for every tick enqueued so far; returns at once (no host wait). */
+int  pp_join(pp_handle h);
+/* pp_join + host wait. */
 int  pp_sync(pp_handle h);
 /* Replaces SetPlanningStatus/SetUdpSendCtrl (Planning.cpp:186,214) and SetDecisionOut (Decision.cpp:203). */
 int  pp_get_plan(pp_handle h, PlanOut* out, int n_scenes);
@@ -144,7 +152,7 @@ int  pp_mean_points(pp_handle h, const GlobalPoint2D* in, int n_in, GlobalPoint2
 int  pp_create_new_path(pp_handle h, const GlobalPoint2D* path, int n, double offset, GlobalPoint2D* out);
 
 /* ---- measurement / multi-GPU plumbing --------------------------------------------------------- */
-/* When on, every kernel launch of pp_plan_tick is bracketed by HIP events on the handle's stream. */
+/* When on, every kernel launch of pp_plan_tick is bracketed by HIP events on the stream it is launched on. */
 int   pp_set_profile(pp_handle h, int on);
 /* Sum of event-measured durations (ms) and launch count of kernel k since the last reset. */
 int   pp_get_kernel_ms(pp_handle h, int k, float* ms_total, int* launches);
@@ -152,7 +160,7 @@ int   pp_reset_kernel_ms(pp_handle h);
 /* Raw device pointer + byte size of an internal buffer, so a caller can scatter inputs into /
  * gather results out of it with RCCL without a host hop. */
 void* pp_device_ptr(pp_handle h, int which, size_t* bytes);
-void* pp_stream(pp_handle h);       /* hipStream_t */
+void* pp_stream(pp_handle h);       /* hipStream_t; ordered after the ticks only after pp_join / pp_sync (see pp_plan_tick) */
 /* sizeof of an ABI struct, for bindings to check their mirror: 0 PlannerConfig, 1 PlannerCaps,
  * 2 SceneIn, 3 SceneState, 4 PlanOut, 5 GridOut, 6 ObPoint, 7 ObMotion, 8 Path_Obs, 9 LocationOut,
  * 10 DecisionOut, 11 LaneView, 12 PlanningOut, 13 PlanningStatus, 14 AimPoint */
@@ -161,7 +169,10 @@ size_t pp_sizeof(int which);
  * and a batch of n_scenes (128 for large batches, narrower - always a multiple of 32 - when the batch does not fill
  * the chip). */
 int   pp_raster_band_rows(int grid_h, int n_scenes);
-int   pp_set_n_scenes(pp_handle h, int n_scenes);  /* after filling the buffers through pp_device_ptr */
+/* After filling the input buffers through pp_device_ptr (an RCCL scatter straight into them): declares what is resident -
+ * scenes, the used part of each pool, whether the motion pool / the lane attribute pool were filled - and checks every
+ * scene's slices against those pools, like pp_set_scenes does. */
+int   pp_set_n_scenes(pp_handle h, int n_scenes, int n_lane_pts, int n_ref_pts, int n_obs_total, int have_motion, int have_lane_attr);
 
 #ifdef __cplusplus
 }

@@ -187,10 +187,17 @@ typedef struct MapDesc {
 #define DMPP_G_GOAL_BLOCKED 4 /* goal cell occupied: no search run */
 #define DMPP_G_PATH_TRUNC 5   /* path longer than max_path cells */
 #define DMPP_G_INTERNAL   6   /* a loop bound of the device search was hit: never expected, reported instead of hanging */
+#define DMPP_G_COST_RANGE 7   /* a successor's f = g + h reached DMPP_F_LIMIT: only `status` is defined (as for OVERFLOW) */
+#define DMPP_G_STATUS_COUNT 8
 
 #define DMPP_JPS_BATCH 4       /* entries of the minimal f taken per step of the jump-point search */
 #define DMPP_DIAG_JUMP 8       /* cells a diagonal jump of the jump-point search looks ahead before it settles for a plain node */
 #define DMPP_OPEN_CAP 512      /* live entries of the jump-point search's open list (LDS resident; 496 is the most any generated scene needs) */
+
+/* f = g + h of an open-list entry must stay below this (the device keeps f/2 in 16 bits, 0xFFFF = dead slot): ~13,000
+ * straight cells of detour.  A push that would reach it ends the search with DMPP_G_COST_RANGE, checked - per push, in
+ * push order - before the open-list capacity. */
+#define DMPP_F_LIMIT 131070
 
 #define DMPP_MAX_LATTICE 17   /* n_lattice Bezier candidates + 1 grid-path candidate */
 

@@ -108,7 +108,8 @@ void orc_rasterise(const PlannerConfig* c, GlobalPoint2D origin, const ObPoint* 
  *             64-lane wave expands four nodes at once.
  *   stop    : goal closed (FOUND, at once: the rest of the step is skipped) | open set empty (NO_PATH)
  *             | n_expanded == max_expansions (LIMIT, at once)
- *             | more than open_cap = min(bucket_cap, DMPP_OPEN_CAP) live entries (OVERFLOW).
+ *             | more than open_cap = min(bucket_cap, DMPP_OPEN_CAP) live entries (OVERFLOW)
+ *             | a successor with f >= DMPP_F_LIMIT (COST_RANGE; per push, tested before the capacity).
  *   path    : from the goal, each closed cell knows its arriving direction and run length; the cells
  *             of every run are written out, start..goal.
  *   n_rounds: number of pops whose f exceeds every f popped before (+1 for the first).
@@ -243,6 +244,7 @@ void orc_grid_search(const PlannerConfig* c, const uint8_t* grid, int start_cell
                 if (!run) continue;
                 const int nx = x + run * DX[s], ny = y + run * DY[s];
                 const int fn = g + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
+                if (fn >= DMPP_F_LIMIT) { status = DMPP_G_COST_RANGE; break; }     /* checked per push, before the capacity */
                 if (n_open >= cap) { status = DMPP_G_OVERFLOW; break; }
                 open[n_open++] = (OEnt){ fn, ny * W + nx, s, run };
                 out->n_pushed++;

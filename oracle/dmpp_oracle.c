@@ -428,9 +428,10 @@ GPSPoint2D orc_GlobalToWGS84(const PlannerConfig* c, GlobalPoint2D p)
 }
 
 /* ------------------------------------------------------------------------------ */
-/* Decision side: LoadRefPath, AroundObstacle, the no-lane-change branch of
- * BehaviorDecision (the lateral sweep), SpeedDecision, RefPath, and the two junction
- * handlers.  The lane-change rule tree (Decision.cpp:1011-1772) is out of scope. */
+/* Decision side: LoadRefPath, AroundObstacle, BehaviorDecision - the no-lane-change
+ * branch (the lateral sweep) and, further down, the lane-change rule tree with
+ * Nav_LaneChange (Decision.cpp:685-738, 1011-1772) -, SpeedDecision, RefPath, and the two
+ * junction handlers. */
 
 typedef struct DecScratch {
     GlobalPoint2D F[DMPP_FRONT_POINTS], R[DMPP_REAR_POINTS], LF[DMPP_FRONT_POINTS], LR[DMPP_REAR_POINTS],

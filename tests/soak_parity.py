@@ -107,14 +107,14 @@ def main():
             if one_shot:
                 bad += compare(plan_g, plan_o, "plan") + compare(st_h, st_o, "state")
                 bad += compare(gout_g["status"], gout_o["status"], "grid.status")
-                keep = gout_o["status"] != 3
+                keep = (gout_o["status"] != 3) & (gout_o["status"] != 7)
                 bad += compare(gout_g[keep], gout_o[keep], "grid")
             elif sync_each or t == n_ticks - 1:
                 pl.sync()
                 plan_g, st_g, gout_g = pl.get_plan(), pl.get_state(), pl.get_grid_out()
                 bad += compare(plan_g, plan_o, "plan") + compare(st_g, st_o, "state")
                 bad += compare(gout_g["status"], gout_o["status"], "grid.status")
-                keep = gout_o["status"] != 3
+                keep = (gout_o["status"] != 3) & (gout_o["status"] != 7)
                 bad += compare(gout_g[keep], gout_o[keep], "grid")
         pl.close()
         it += 1

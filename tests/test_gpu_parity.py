@@ -42,7 +42,7 @@ def _assert_tick(res, tag=""):
     bad = compare(plan_g, plan_o, "plan") + compare(st_g, st_o, "state")
     if gout_g is not None:
         bad += compare(gout_g["status"], gout_o["status"], "grid.status")
-        keep = gout_o["status"] != 3          # DMPP_G_OVERFLOW: only the status is specified
+        keep = (gout_o["status"] != 3) & (gout_o["status"] != 7)   # DMPP_G_OVERFLOW / COST_RANGE: only the status is specified
         bad += compare(gout_g[keep], gout_o[keep], "grid")
     assert not bad, tag + "\n" + "\n".join(bad[:20])
 
@@ -641,7 +641,7 @@ def test_bench_two_ranks_rehearsal(dm, oracle, tmp_path):
     got = np.load(dump)
     cfg = dm.default_config(grid)
     threads = min(64, os.cpu_count() or 8)
-    counts = np.zeros(6, np.int64)
+    counts = np.zeros(dm.G_STATUS_COUNT, np.int64)
     for rk in range(2):                                    # rank rk's shard is scenes rk*n .. rk*n + n - 1
         sc = dm.gen_scenes(cfg, rk * n, n, n_obs, junction_every=8)
         st = sc["state"].copy()
@@ -650,7 +650,7 @@ def test_bench_two_ranks_rehearsal(dm, oracle, tmp_path):
         bad = (compare(got["plan"][sl], plan_o, "plan") + compare(got["state"][sl], st, "state")
                + compare(got["grid_out"][sl], gout_o, "grid"))
         assert not bad, f"rank {rk}:\n" + "\n".join(bad[:10])
-        counts += np.bincount(gout_o["status"], minlength=6)
+        counts += np.bincount(gout_o["status"], minlength=dm.G_STATUS_COUNT)
     assert line["search_status_counts"] == counts.tolist()
     assert line["searched_scenes"] == int(counts.sum() - counts[dm.G_GOAL_BLOCKED])
 
@@ -689,3 +689,121 @@ def test_no_candidate_at_all(dm, oracle):
     none = gout_o["n_candidates"] == 0
     assert none.any() and (~none).any(), np.bincount(gout_o["status"])
     assert not gout_o["best_path"]["x"][none].any()
+
+
+@pytest.mark.parametrize("n_walls,want", [(5, 0), (7, 7)])
+def test_cost_range_serpentine_2048(dm, oracle, n_walls, want):
+    """f = g + h close to and beyond DMPP_F_LIMIT (the device keeps f/2 in 16 bits): five serpentine walls on 2048 x 2048
+    cost 124,162 and must match the oracle in every field, expansion order included; seven walls exceed the limit and end
+    with DMPP_G_COST_RANGE in both (only the status is defined there).  Thousands of closed cells: the closed set spills
+    from the LDS hash to HBM."""
+    from grid_scenes import serpentine
+    cfg = dm.default_config(2048)
+    cfg["max_expansions"] = 400000
+    cfg["max_path"] = 32768
+    sc = serpentine(dm, cfg, n_walls)
+    pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=1, order_cap=8192)
+    _assert_tick(res[0], f"{n_walls} walls")
+    gout_o = res[0][5]
+    assert int(gout_o["status"][0]) == want
+    if want == 0:
+        assert int(gout_o["path_cost"][0]) > 120000 and int(gout_o["n_expanded"][0]) > 768
+        st1 = sc["state"].copy()
+        _, go, grid_o, order_o, path_o = oracle.plan_tick_one(cfg, sc, 0, st1, order_cap=8192)
+        assert (pl.get_order(0, int(go["n_expanded"])) == order_o).all()
+        assert (pl.get_path(0, int(go["path_len"])) == path_o).all()
+
+
+def test_unsynced_ticks_then_grid_and_stage_switch(dm, oracle):
+    """What a caller may do between ticks without a host sync (the three-stream tick, n >= 256): read the grid of the last
+    tick (pp_get_grid expands the bitmaps the rasteriser wrote on another stream), then switch the grid stage off and on
+    again - Decision + Planning move to the handle's stream and back to the front chain - and keep ticking."""
+    cfg = dm.default_config(128)
+    cfg["dynamic_obstacles"] = 1
+    n, n_obs = 384, 128                                    # >= 128 obstacles per scene: consecutive searches overlap on two streams
+    sc = dm.gen_scenes(cfg, 777, n, n_obs, junction_every=5)
+    pl = dm.Planner(cfg, max_scenes=n, max_obs_total=n * n_obs)
+    pl.set_scenes(sc)
+    pl.set_state(sc["state"])
+    st_o = sc["state"].copy()
+    cfg_off = cfg.copy()
+    cfg_off["grid_stage"] = 0
+    plan_o = gout_o = grids_o = None
+    for phase, (c_, ticks) in enumerate([(cfg, 3), (cfg_off, 2), (cfg, 2), (cfg_off, 1), (cfg, 3)]):
+        pl.set_config(c_)
+        for _ in range(ticks):
+            pl.tick(sync=False)
+            plan_o, g2, gr2 = oracle.plan_tick_batch(c_, sc, st_o, n_threads=8, want_grid=bool(c_["grid_stage"][0]),
+                                                     keep_grids=bool(c_["grid_stage"][0]))
+            if c_["grid_stage"][0]:
+                gout_o, grids_o = g2, gr2
+        if c_["grid_stage"][0]:
+            for s in (0, 5, n - 1):                         # no sync before this: pp_get_grid orders itself after the rasteriser
+                assert (pl.get_grid(s) == grids_o[s]).all(), (phase, s)
+            bad = compare(pl.get_grid_out(), gout_o, "grid")
+            assert not bad, f"phase {phase}\n" + "\n".join(bad[:10])
+        bad = compare(pl.get_plan(), plan_o, "plan") + compare(pl.get_state(), st_o, "state")
+        assert not bad, f"phase {phase}\n" + "\n".join(bad[:10])
+
+
+def test_scene_slices_are_validated(dm):
+    """A SceneIn whose obstacle / lane / refpath slice leaves its pool is refused by pp_set_scenes (PP_ERR_ARG): nothing is
+    left resident and no kernel ever follows the slice.  An empty slice may carry any offset."""
+    cfg = dm.default_config(128)
+    n, n_obs = 8, 6
+    pl = dm.Planner(cfg, max_scenes=n, max_obs_total=n * n_obs)
+    for field, sub, val in [("obs_off", None, n * n_obs - 2), ("obs_n", None, -1), ("obs_off", None, -3),
+                            ("lanes", "cur_n", 10 ** 7), ("lanes", "left_off", 2 ** 30), ("ref_off", None, n * dm.GEN_REF_PTS)]:
+        sc = dm.gen_scenes(cfg, 0, n, n_obs, junction_every=2)
+        si = sc["scene_in"]
+        if sub:
+            if sub == "left_off":
+                si["lanes"]["left_n"][3] = 5
+            si[field][sub][3] = val
+        else:
+            if field == "ref_off":
+                si["ref_n"][3] = 4
+            si[field][3] = val
+        with pytest.raises(dm.PlannerError, match="outside its pool"):
+            pl.set_scenes(sc)
+        pl.tick(sync=True)                                   # nothing resident: a no-op, not a fault
+    sc = dm.gen_scenes(cfg, 0, n, n_obs, junction_every=2)
+    sc["scene_in"]["lanes"]["left_off"][2] = 2 ** 30         # empty slice, wild offset: accepted
+    sc["scene_in"]["lanes"]["left_n"][2] = 0
+    pl.set_scenes(sc)
+    pl.tick(sync=True)
+
+
+def test_device_pointer_inputs_without_a_motion_pool(dm, oracle):
+    """Inputs written straight into the handle's buffers (pp_device_ptr, as an RCCL scatter would) and declared with
+    pp_set_n_scenes: without a motion pool the obstacles stand still even when cfg.dynamic_obstacles is set (velocities
+    nobody uploaded are zero, not uninitialised memory); with one they move."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    cfg = dm.default_config(128)
+    cfg["dynamic_obstacles"] = 1
+    n, n_obs = 32, 12
+    sc = dm.gen_scenes(cfg, 31, n, n_obs, junction_every=4)
+    for with_motion in (False, True):
+        pl = dm.Planner(cfg, max_scenes=n, max_obs_total=n * n_obs)
+        bufs = [(dm.BUF_SCENE_IN, sc["scene_in"]), (dm.BUF_LANE_POOL, sc["lane_pool"]), (dm.BUF_LANE_ATTR, sc["attr_pool"]),
+                (dm.BUF_REF_POOL, sc["ref_pool"]), (dm.BUF_OBS_POOL, sc["obs_pool"]), (dm.BUF_STATE, sc["state"])]
+        if with_motion:
+            bufs.append((dm.BUF_MOT_POOL, sc["mot_pool"]))
+        for which, arr in bufs:
+            ptr, size = pl.device_ptr(which)
+            raw = np.frombuffer(arr.tobytes(), np.uint8).copy()
+            assert raw.size <= size
+            assert hip.hipMemcpy(C.c_void_p(ptr), C.c_void_p(raw.ctypes.data), C.c_size_t(raw.size), 1) == 0     # hipMemcpyHostToDevice
+        dm._check(pl.lib.pp_set_n_scenes(pl.h, n, len(sc["lane_pool"]), len(sc["ref_pool"]), n * n_obs, int(with_motion), 1))
+        pl.n = n
+        sc_o = dict(sc)
+        if not with_motion:
+            sc_o["mot_pool"] = None
+        st_o = sc["state"].copy()
+        for _ in range(3):
+            pl.tick(sync=True)
+            plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc_o, st_o, n_threads=8, want_grid=True)
+        bad = compare(pl.get_plan(), plan_o, "plan") + compare(pl.get_state(), st_o, "state") + compare(pl.get_grid_out(), gout_o, "grid")
+        assert not bad, f"with_motion={with_motion}\n" + "\n".join(bad[:10])
+        pl.close()

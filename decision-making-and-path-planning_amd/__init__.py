@@ -40,7 +40,7 @@ LaneView = _dt([("cur_off", i4), ("cur_n", i4), ("left_off", i4), ("left_n", i4)
 LocationOut = _dt([("globalpoint", GlobalPoint3D), ("velocity", f8), ("pos", i4), ("road_num", i4), ("lane_num", i4),
                    ("last_roadnum", i4), ("next_roadnum", i4), ("last_lanenum", i4), ("next_lanenum", i4),
                    ("path_num", i4), ("id", i4, (LANESUM,))])
-DecisionOut = _dt([("velocity_expect", f8), ("behavior", i4), ("target_roadnum", i4), ("target_lanenum", i4),
+DecisionOutPod = _dt([("velocity_expect", f8), ("behavior", i4), ("target_roadnum", i4), ("target_lanenum", i4),
                    ("light", i4), ("behavior_to_dlg", i4), ("refpath_n", i4)])
 Obs_To_Veh = _dt([("dis_lat", f8), ("dis_lng", f8)])
 Path_Obs = _dt([("Ob_Pose", Obs_To_Veh), ("Ob_Attr", ObPoint), ("Obs_flag", i4), ("Ob_Pathid", i4)])
@@ -58,7 +58,7 @@ SceneState = _dt([("last_Bpoints", GlobalPoint2D, (PATH_POINTS,)), ("aimpoint_fa
                   ("d_his_behavior", i4), ("d_his_light_status", i4), ("d_his_target_lanenum", i4),
                   ("obsavoid_time", u4), ("no_obsaviod_time", u4), ("frontobs_time", u4), ("tick", i4), ("_pad", i4),
                   ("z_velocity_expect", f8), ("leftlight_time", f8), ("rightlight_time", f8)])
-SceneIn = _dt([("loc", LocationOut), ("dec", DecisionOut), ("lanes", LaneView), ("ref_off", i4), ("ref_n", i4),
+SceneIn = _dt([("loc", LocationOut), ("dec", DecisionOutPod), ("lanes", LaneView), ("ref_off", i4), ("ref_n", i4),
                ("obs_off", i4), ("obs_n", i4), ("stub_attribute", i4), ("_pad", i4), ("out_lane_no", u2, (LANESUM,)),
                ("period_last", f8), ("grid_origin", GlobalPoint2D),
                ("goal", GlobalPoint2D)])
@@ -68,7 +68,7 @@ GridOut = _dt([("order_digest", u8), ("status", i4), ("n_expanded", i4), ("n_pus
                ("cand_curv", f8, (MAX_LATTICE,)), ("cand_prog", f8, (MAX_LATTICE,)),
                ("best_path", GlobalPoint2D, (PATH_POINTS,))])
 PlanOut = _dt([("result", PlanningOut), ("show", PlanningStatus), ("road_points", GlobalPoint2D, (PATH_POINTS,)),
-               ("around", Path_Obs, (6,)), ("dec", DecisionOut), ("ob_dis_lat", f8), ("ob_dis_lng", f8), ("ob", ObPoint),
+               ("around", Path_Obs, (6,)), ("dec", DecisionOutPod), ("ob_dis_lat", f8), ("ob_dis_lng", f8), ("ob", ObPoint),
                ("ob_flag", i4), ("ob_pathid", i4), ("sweep_side", i4), ("sweep_index", i4), ("navi_lanechg", i4),
                ("navi_lanechg_times", i4)])
 PlannerConfig = _dt([("ROAD_FARAIM_MAX", f8), ("ROAD_FARAIM_MIN", f8), ("PRE_INTER_FARAIM", f8), ("INTER_FARAIM", f8),
@@ -86,7 +86,7 @@ MapLane = _dt([("point_off", i4), ("n_points", i4), ("lane_sum", i4), ("_pad", i
 MapJunction = _dt([("last_road", i4), ("next_road", i4), ("last_lane", i4), ("next_lane", i4), ("point_off", i4), ("n_points", i4)])
 
 _SIZEOF_ORDER = [PlannerConfig, PlannerCaps, SceneIn, SceneState, PlanOut, GridOut, ObPoint, ObMotion, Path_Obs,
-                 LocationOut, DecisionOut, LaneView, PlanningOut, PlanningStatus, AimPoint, MapLane, MapJunction]
+                 LocationOut, DecisionOutPod, LaneView, PlanningOut, PlanningStatus, AimPoint, MapLane, MapJunction]
 
 
 class MapDesc(C.Structure):          # include/dmpp_types.h: the map store handed to pp_set_map

@@ -968,7 +968,7 @@ size_t pp_sizeof(int which)
     case 0: return sizeof(PlannerConfig); case 1: return sizeof(PlannerCaps); case 2: return sizeof(SceneIn);
     case 3: return sizeof(SceneState); case 4: return sizeof(PlanOut); case 5: return sizeof(GridOut);
     case 6: return sizeof(ObPoint); case 7: return sizeof(ObMotion); case 8: return sizeof(Path_Obs);
-    case 9: return sizeof(LocationOut); case 10: return sizeof(DecisionOut); case 11: return sizeof(LaneView);
+    case 9: return sizeof(LocationOut); case 10: return sizeof(DecisionOutPod); case 11: return sizeof(LaneView);
     case 12: return sizeof(PlanningOut); case 13: return sizeof(PlanningStatus); case 14: return sizeof(AimPoint);
     case 15: return sizeof(MapLane); case 16: return sizeof(MapJunction); case 17: return sizeof(MapDesc);
     default: return 0;

@@ -612,7 +612,7 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         __syncthreads();
     }
     if (tid == 0) {       // Decision.cpp:187-201
-        DecisionOut d;
+        DecisionOutPod d;
         d.velocity_expect = st.z_velocity_expect; d.behavior = st.z_behavior; d.target_roadnum = st.z_target_roadnum;
         d.target_lanenum = st.z_target_lanenum; d.light = st.z_light_status; d.behavior_to_dlg = st.z_behavior_to_dlg;
         d.refpath_n = sh.n_ref;
@@ -656,7 +656,7 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     if (m <= kMaxObsLds) { for (int j = tid; j < m; j += kBlock) sh.obs[j] = gobs[j]; obs = sh.obs; }
 
     // DecisionOut: published by k_decision into PlanOut.dec, or the caller's (decision stage off)
-    DecisionOut dec;
+    DecisionOutPod dec;
     const GlobalPoint2D* refpath;
     if (c.decision_stage) { dec = po.dec; refpath = dec_ref + (size_t)scene * DMPP_MAX_REFPATH; }
     else {

@@ -12,7 +12,7 @@ public:
 
     void SetMap(const LaneMap& map) { m_map = map; }
     // junction_polyline: decision_InterMapData[...] for pos 1/2 (Decision.cpp:348); stub_attribute: Decision.cpp:385
-    DecisionOutV decide(const LocationOut& location, const vector<ObPoint>& obstacles,
+    DecisionOut decide(const LocationOut& location, const vector<ObPoint>& obstacles,
                         const vector<GlobalPoint2D>& junction_polyline = {}, int stub_attribute = 0,
                         Path_Obs around[6] = nullptr, double period_last_ms = 100.0 /* z_period_last, Decision.cpp:137 */);
     const SceneState& State() const { return m_state; }

@@ -19,7 +19,7 @@ struct OneScene {
     vector<GlobalPoint2D> ref;
     vector<ObPoint> obs;
 };
-void build_scene(const LaneMap& m, const LocationOut& loc, const DecisionOut& dec, const vector<GlobalPoint2D>& ref,
+void build_scene(const LaneMap& m, const LocationOut& loc, const DecisionOutPod& dec, const vector<GlobalPoint2D>& ref,
                  const vector<ObPoint>& obs, int stub_attribute, OneScene& s, double period_last_ms = 100.0)
 {
     std::memset(&s.in, 0, sizeof(s.in));
@@ -52,8 +52,15 @@ int run_scene(OneScene& s, SceneState& st, PlanOut& out, GridOut* grid, bool dec
     PlannerConfig c = CShare::Config();
     c.decision_stage = decision_stage ? 1 : 0;
     if (!grid) c.grid_stage = 0;
-    int rc = pp_set_config(h, &c);
-    if (rc) return rc;
+    // decide() and plan() alternate between two stage settings: pp_set_config drains the handle, so it is only called
+    // when the configuration really differs from the one the handle has
+    static PlannerConfig applied; static bool have_applied = false;
+    int rc = PP_OK;
+    if (!have_applied || std::memcmp(&applied, &c, sizeof(c)) != 0) {
+        rc = pp_set_config(h, &c);
+        if (rc) { have_applied = false; return rc; }
+        applied = c; have_applied = true;
+    }
     return pp_plan_tick_batch(h, 1, &s.in, s.obs.data(), nullptr, (int)s.obs.size(), s.lanes.data(), s.attr.data(), (int)s.lanes.size(),
                               s.ref.data(), (int)s.ref.size(), &st, &out, grid);
 }
@@ -130,15 +137,16 @@ void CPlanning::Reset()
     his_behavior = 1; path_near_id = path_front_near_id = 0;
 }
 
-void CPlanning::tick(const DecisionOutV& dec, const LocationOut& loc, const vector<ObPoint>& obs, SceneState& st,
+void CPlanning::tick(const DecisionOut& dec, const LocationOut& loc, const vector<ObPoint>& obs, SceneState& st,
                      PlanOut& out, GridOut* grid, bool decision_stage)
 {
     OneScene s;
     build_scene(m_map, loc, dec, dec.refpath, obs, 0, s);
+    if (m_frame) { s.in.grid_origin = m_origin; s.in.goal = m_goal; }
     note(run_scene(s, st, out, grid, decision_stage));
 }
 
-void CPlanning::plan(const DecisionOutV& decision, const LocationOut& location, const VehStatus&, const vector<ObPoint>& obstacles,
+void CPlanning::plan(const DecisionOut& decision, const LocationOut& location, const VehStatus&, const vector<ObPoint>& obstacles,
                      PlanningOut& result, PlanningStatus& show, GlobalPoint2D road_points[], GridOut* grid)
 {
     PlanOut out{};
@@ -157,21 +165,21 @@ void CPlanning::plan(const DecisionOutV& decision, const LocationOut& location, 
 
 // The stage methods below run the device tick on a SCRATCH copy of the state and return the stage's own
 // outputs (each of these stages stores its outputs in SceneState untouched by later stages).
-void CPlanning::Calculate_aim_dis(DecisionOutV dec, LocationOut loc, VehStatus, FLOAT& far_, FLOAT& near_)
+void CPlanning::Calculate_aim_dis(DecisionOut dec, LocationOut loc, VehStatus, FLOAT& far_, FLOAT& near_)
 {
     SceneState st = m_state; PlanOut out{};
     tick(dec, loc, {}, st, out, nullptr, false);
     far_ = st.faraim_dis; near_ = st.nearaim_dis;
     faraim_dis = far_; nearaim_dis = near_;           // the reference writes the members (Planning.cpp:118)
 }
-void CPlanning::SearchAimPoint(DecisionOutV dec, LocationOut loc, VehStatus, AimPoint& far_, AimPoint& near_)
+void CPlanning::SearchAimPoint(DecisionOut dec, LocationOut loc, VehStatus, AimPoint& far_, AimPoint& near_)
 {
     SceneState st = m_state; PlanOut out{};
     st.aimpoint_far = far_; st.aimpoint_near = near_;  // branches that assign nothing keep the caller's values
     tick(dec, loc, {}, st, out, nullptr, false);
     far_ = st.aimpoint_far; near_ = st.aimpoint_near;
 }
-void CPlanning::InitialPlanning(DecisionOutV, LocationOut loc, VehStatus, const AimPoint aimpoint_far, const AimPoint,
+void CPlanning::InitialPlanning(DecisionOut, LocationOut loc, VehStatus, const AimPoint aimpoint_far, const AimPoint,
                                 GlobalPoint2D Bezier_points[])
 { BezierPlanning(loc.globalpoint, aimpoint_far.Aim_point, Bezier_points, DMPP_PATH_POINTS); }           // Planning.cpp:596-611
 void CPlanning::GetVhclLocalState(LocationOut loc, const GlobalPoint2D last_Bpoints[], double& mindist_lat, double& dir_err,
@@ -181,12 +189,12 @@ void CPlanning::GetVhclLocalState(LocationOut loc, const GlobalPoint2D last_Bpoi
     std::memcpy(st.last_Bpoints, last_Bpoints, sizeof(st.last_Bpoints));
     st.count = 1;                                      // not the first tick: no InitialPlanning
     st.path_near_id = mindist_id;
-    DecisionOutV dec; dec.behavior = st.his_behavior; dec.target_lanenum = loc.lane_num;
+    DecisionOut dec; dec.behavior = st.his_behavior; dec.target_lanenum = loc.lane_num;
     tick(dec, loc, {}, st, out, nullptr, false);
     mindist_lat = st.path_lat_dis; dir_err = st.path_dir_err; mindist_id = st.path_near_id;
     front_mindist_id = st.path_front_near_id; remain = st.remain_dis;
 }
-bool CPlanning::UpdatePlanJudge(const DecisionOutV dec, const LocationOut loc, const int last_behavior, int& afreshcause)
+bool CPlanning::UpdatePlanJudge(const DecisionOut dec, const LocationOut loc, const int last_behavior, int& afreshcause)
 {
     const double in[6] = {(double)last_behavior, (double)dec.behavior, (double)loc.pos, path_lat_dis, path_dir_err, remain_dis};
     double out[2] = {0, 0};
@@ -194,7 +202,7 @@ bool CPlanning::UpdatePlanJudge(const DecisionOutV dec, const LocationOut loc, c
     afreshcause = (int)out[1];
     return out[0] != 0;
 }
-void CPlanning::PathPlanning(const DecisionOutV dec, int, LocationOut loc, const AimPoint aimpoint_far, const AimPoint,
+void CPlanning::PathPlanning(const DecisionOut dec, int, LocationOut loc, const AimPoint aimpoint_far, const AimPoint,
                              GlobalPoint2D road_points[])
 {   // Planning.cpp:845-877
     if (loc.pos == 0) BezierPlanning(loc.globalpoint, aimpoint_far.Aim_point, road_points, DMPP_PATH_POINTS);
@@ -206,7 +214,7 @@ void CPlanning::PathPlanning(const DecisionOutV dec, int, LocationOut loc, const
         MeanPoints(ref.empty() ? &dummy : ref.data(), na, road_points, DMPP_PATH_POINTS);
     } else std::memset(road_points, 0, sizeof(GlobalPoint2D) * DMPP_PATH_POINTS);
 }
-void CPlanning::SpeedPlanning(const bool ob_flag, const DecisionOutV dec, const LocationOut loc, const double mindist_lon,
+void CPlanning::SpeedPlanning(const bool ob_flag, const DecisionOut dec, const LocationOut loc, const double mindist_lon,
                               const double, const FLOAT far_, double& brake_speed, bool& accf, double& desacc)
 {
     const double in[8] = {(double)loc.pos, ob_flag ? 1.0 : 0.0, mindist_lon, (double)far_, dec.velocity_expect, brake_speed,
@@ -233,22 +241,100 @@ CDecision& CDecision::Instance() { static CDecision theDecision; return theDecis
 BYTE CDecision::startCDecisionThread() { return Device() ? 1 : 0; }
 void CDecision::Reset() { pp_init_state(&m_state, 1); }
 
-DecisionOutV CDecision::decide(const LocationOut& location, const vector<ObPoint>& obstacles,
+DecisionOut CDecision::decide(const LocationOut& location, const vector<ObPoint>& obstacles,
                                const vector<GlobalPoint2D>& junction_polyline, int stub_attribute, Path_Obs around[6],
                                double period_last_ms)
 {
     OneScene s;
-    DecisionOut none{};
+    DecisionOutPod none{};
     build_scene(m_map, location, none, junction_polyline, obstacles, stub_attribute, s, period_last_ms);
     if (m_state.tick == 0 && m_state.z_target_lanenum != location.lane_num) {
         m_state.z_target_lanenum = location.lane_num; m_state.d_his_target_lanenum = location.lane_num;
     }
     PlanOut out{};
     note(run_scene(s, m_state, out, nullptr, true));
-    DecisionOutV d;
-    static_cast<DecisionOut&>(d) = out.dec;
+    DecisionOut d;
+    static_cast<DecisionOutPod&>(d) = out.dec;
     d.refpath.resize((size_t)std::max(out.dec.refpath_n, 0));
     if (!d.refpath.empty()) note(pp_get_refpath(Device(), 0, d.refpath.data(), (int)d.refpath.size()));
     if (around) std::memcpy(around, out.around, sizeof(out.around));
     return d;
 }
+
+// ------------------------------------------------------------------------------------- C entry points
+// The class surface for callers without a C++ compiler at hand (the ctypes harness of tests/ and bench.py): each function
+// below is one or two calls on the singletons above and nothing else.
+extern "C" {
+
+struct DmppHostMembers {          // the public members of CPlanning (Planning.h:42-52) after a plan()
+    double path_lat_dis, remain_dis, path_dir_err, brakespeed, des_acc;
+    int32_t afresh_planning, afresh_cause, path_near_id, path_front_near_id, his_behavior, acc_flag;
+};
+
+int dmpp_host_start(void)
+{ return (CDecision::Instance().startCDecisionThread() && CPlanning::Instance().startCPlanningThread()) ? 0 : CShare::LastStatus().code; }
+
+const char* dmpp_host_error(void) { return CShare::LastStatus().text; }
+
+PlannerConfig* dmpp_host_config(void) { return &CShare::Config(); }
+
+void dmpp_host_reset(int lane_num)
+{
+    CDecision::Instance().Reset(); CPlanning::Instance().Reset();
+    (void)lane_num;
+}
+
+void dmpp_host_set_map(const GlobalPoint3D* cur, int n_cur, const GlobalPoint3D* left, int n_left, const GlobalPoint3D* right, int n_right,
+                       int lane_sum, int lanechg_attribute, double lane_width, const uint8_t* cur_attr, int n_attr, const uint16_t* out_lane_no)
+{
+    LaneMap m;
+    if (n_cur > 0) m.cur.assign(cur, cur + n_cur);
+    if (n_left > 0) m.left.assign(left, left + n_left);
+    if (n_right > 0) m.right.assign(right, right + n_right);
+    m.lane_sum = lane_sum; m.lanechg_attribute = lanechg_attribute; m.lane_width = lane_width;
+    if (n_attr > 0) m.cur_lanechg_attribute.assign(cur_attr, cur_attr + n_attr);
+    for (int i = 0; i < DMPP_LANESUM; i++) m.out_lane_no[i] = out_lane_no ? out_lane_no[i] : 0;
+    CDecision::Instance().SetMap(m); CPlanning::Instance().SetMap(m);
+}
+
+// CDecision::decide -> CPlanning::plan: one pass of the two reference threads (Decision.cpp:172-205, Planning.cpp:114-223)
+int dmpp_host_tick(const LocationOut* loc, const ObPoint* obs, int n_obs, const GlobalPoint2D* junction, int n_junction,
+                   int stub_attribute, double period_last_ms,
+                   DecisionOutPod* dec_out, GlobalPoint2D* refpath_out, int refpath_cap, Path_Obs* around_out,
+                   PlanningOut* result, PlanningStatus* show, GlobalPoint2D* road_points, DmppHostMembers* members, GridOut* grid)
+{
+    vector<ObPoint> o; if (n_obs > 0) o.assign(obs, obs + n_obs);
+    vector<GlobalPoint2D> j; if (n_junction > 0) j.assign(junction, junction + n_junction);
+    DecisionOut d = CDecision::Instance().decide(*loc, o, j, stub_attribute, around_out, period_last_ms);
+    if (CShare::LastStatus().code) return CShare::LastStatus().code;
+    if (dec_out) { *dec_out = d; dec_out->refpath_n = (int32_t)d.refpath.size(); }
+    for (int i = 0; i < refpath_cap && i < (int)d.refpath.size(); i++) refpath_out[i] = d.refpath[(size_t)i];
+    CPlanning& pl = CPlanning::Instance();
+    pl.plan(d, *loc, VehStatus{}, o, *result, *show, road_points, grid);
+    if (members) {
+        members->path_lat_dis = pl.path_lat_dis; members->remain_dis = pl.remain_dis; members->path_dir_err = pl.path_dir_err;
+        members->brakespeed = pl.brakespeed; members->des_acc = pl.des_acc; members->afresh_planning = pl.afresh_planning;
+        members->afresh_cause = pl.afresh_cause; members->path_near_id = pl.path_near_id; members->path_front_near_id = pl.path_front_near_id;
+        members->his_behavior = pl.his_behavior; members->acc_flag = pl.acc_flag;
+    }
+    return CShare::LastStatus().code;
+}
+
+// CPlanning::plan alone, on a DecisionOut the caller holds (the p50 of the class surface is quoted on this call)
+int dmpp_host_plan(const DecisionOutPod* dec, const GlobalPoint2D* refpath, int n_refpath, const LocationOut* loc, const ObPoint* obs, int n_obs,
+                   PlanningOut* result, PlanningStatus* show, GlobalPoint2D* road_points, GridOut* grid)
+{
+    DecisionOut d; static_cast<DecisionOutPod&>(d) = *dec;
+    if (n_refpath > 0) d.refpath.assign(refpath, refpath + n_refpath);
+    vector<ObPoint> o; if (n_obs > 0) o.assign(obs, obs + n_obs);
+    CPlanning::Instance().plan(d, *loc, VehStatus{}, o, *result, *show, road_points, grid);
+    return CShare::LastStatus().code;
+}
+
+void dmpp_host_set_grid_frame(double ox, double oy, double gx, double gy)
+{ CPlanning::Instance().SetGridFrame(GlobalPoint2D{ox, oy}, GlobalPoint2D{gx, gy}); }
+
+const SceneState* dmpp_host_planning_state(void) { return &CPlanning::Instance().State(); }
+const SceneState* dmpp_host_decision_state(void) { return &CDecision::Instance().State(); }
+
+}  // extern "C"

@@ -22,11 +22,13 @@ typedef double         DOUBLE;
 // VehStatus is copied around but never read on the path (Planning.cpp:106)
 struct VehStatus { double reserved[4]; };
 
-// DecisionOut as the reference builds it (Decision.cpp:187-196): the POD of the C-ABI plus the refpath vector
-struct DecisionOutV : public DecisionOut {
+// DecisionOut exactly as the reference builds and passes it (Decision.cpp:187-196; Planning.h:57-75 take it by value):
+// period_max, period_last, behavior, target_roadnum, target_lanenum, light, velocity_expect, refpath, behavior_to_dlg.
+// The scalar fields are those of the C-ABI's DecisionOutPod (refpath_n is kept equal to refpath.size() at the boundary).
+struct DecisionOut : public DecisionOutPod {
     double period_max = 0, period_last = 0;
     vector<GlobalPoint2D> refpath;
-    DecisionOutV() : DecisionOut{} {}
+    DecisionOut() : DecisionOutPod{} {}
 };
 
 // planning_MapData[road][lane] as this boundary sees it: the current lane and its neighbours

@@ -31,7 +31,7 @@ int main()
     dec.SetMap(map); pl.SetMap(map);
     PlanningOut result; PlanningStatus show; GlobalPoint2D road[DMPP_PATH_POINTS];
     for (int t = 0; t < 5; t++) {
-        DecisionOutV d = dec.decide(in.loc, obs);
+        DecisionOut d = dec.decide(in.loc, obs);
         pl.plan(d, in.loc, VehStatus{}, obs, result, show, road);
         std::printf("tick %d: behavior %d refpath %zu  desspd %.3f  radius %.2f  replan %d cause %d  near_ob %.2f\n", t, d.behavior,
                     d.refpath.size(), result.desspd, result.radius, (int)pl.afresh_planning, pl.afresh_cause, show.near_ob_dist);
@@ -40,7 +40,7 @@ int main()
     // helper methods of the reference surface, each evaluated on the device
     GlobalPoint2D a{0, 0}, b{1, 1}, c{0, 1};
     const double ang = pl.GetRoadAngle(a, b), err = pl.GetAngleErr(350, 10), lat = pl.GetLatDis(c, a, b), dist = pl.CalcDistance(a, b);
-    int cause = 0; const bool judge = pl.UpdatePlanJudge(DecisionOutV(), in.loc, 7, cause);
+    int cause = 0; const bool judge = pl.UpdatePlanJudge(DecisionOut(), in.loc, 7, cause);
     std::printf("GetRoadAngle %.6f GetAngleErr %.1f GetLatDis %.6f CalcDistance %.6f UpdatePlanJudge %d/%d CalculateRadius %.3f\n",
                 ang, err, lat, dist, (int)judge, cause, pl.CalculateRadius());
     const bool ok = std::fabs(ang - 45.0) < 1e-9 && err == 20.0 && std::fabs(lat - std::sqrt(0.5)) < 1e-12 &&

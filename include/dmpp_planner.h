@@ -163,7 +163,7 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes);
 void* pp_stream(pp_handle h);       /* hipStream_t; ordered after the ticks only after pp_join / pp_sync (see pp_plan_tick) */
 /* sizeof of an ABI struct, for bindings to check their mirror: 0 PlannerConfig, 1 PlannerCaps,
  * 2 SceneIn, 3 SceneState, 4 PlanOut, 5 GridOut, 6 ObPoint, 7 ObMotion, 8 Path_Obs, 9 LocationOut,
- * 10 DecisionOut, 11 LaneView, 12 PlanningOut, 13 PlanningStatus, 14 AimPoint */
+ * 10 DecisionOutPod, 11 LaneView, 12 PlanningOut, 13 PlanningStatus, 14 AimPoint */
 size_t pp_sizeof(int which);
 /* Host-side launch geometry, callable without a GPU (tests): rows per band of the rasteriser for a grid of grid_h rows
  * and a batch of n_scenes (128 for large batches, narrower - always a multiple of 32 - when the batch does not fill

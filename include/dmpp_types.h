@@ -69,16 +69,17 @@ typedef struct LocationOut {
     int32_t id[DMPP_LANESUM];         /* ego point id on each lane                  Planning.cpp:338     */
 } LocationOut;                                                              /* 96 B */
 
-/* DecisionOut minus the std::vector: refpath is flattened to (offset,len) into a
- * point pool at the ABI (Decision.cpp:187-196). */
-typedef struct DecisionOut {
+/* DecisionOut (Decision.cpp:187-196) minus the std::vector and the two period fields: refpath is flattened to
+ * (offset,len) into a point pool at the C-ABI.  The C++ host surface (host/dmpp_share.hpp) declares
+ * `struct DecisionOut` - the type the reference's methods take, Planning.h:57-75 - on top of this POD. */
+typedef struct DecisionOutPod {
     double  velocity_expect;
     int32_t behavior;         /* 1 keep,2 left chg,3 right chg,4 left avoid,5 right avoid,6 grid search (Decision.h:36) */
     int32_t target_roadnum, target_lanenum;
     int32_t light;            /* 0 none,1 left,2 right,3 hazard (Decision.h:39) */
     int32_t behavior_to_dlg;
     int32_t refpath_n;        /* number of valid refpath points (<= DMPP_MAX_REFPATH) */
-} DecisionOut;                                                              /* 32 B */
+} DecisionOutPod;                                                           /* 32 B */
 
 /* Obs_To_Veh / Path_Obs: Decision.cpp:847-850 */
 typedef struct Obs_To_Veh { double dis_lat, dis_lng; } Obs_To_Veh;
@@ -139,7 +140,7 @@ typedef struct SceneState {
 /* ---- per-scene per-tick input ---------------------------------------------------- */
 typedef struct SceneIn {
     LocationOut loc;          /* app->GetLocationOut()   Planning.cpp:101 */
-    DecisionOut dec;          /* app->GetDesicionOut()   Planning.cpp:96  — used as is when the decision stage is off */
+    DecisionOutPod dec;       /* app->GetDesicionOut()   Planning.cpp:96  — used as is when the decision stage is off */
     LaneView    lanes;        /* slice of the lane-point pool standing in for planning_MapData */
     int32_t ref_off, ref_n;   /* DecisionOut.refpath / junction polyline: slice of the refpath pool */
     int32_t obs_off, obs_n;   /* app->GetObj() snapshot: slice of the obstacle pool (Planning.cpp:111) */
@@ -223,7 +224,7 @@ typedef struct PlanOut {
     PlanningStatus show;        /* what SetPlanningStatus receives, Planning.cpp:186 */
     GlobalPoint2D  road_points[DMPP_PATH_POINTS];  /* the 200-point path of this tick */
     Path_Obs       around[6];   /* F,R,LF,LR,RF,RR  (Decision.cpp:847-880) */
-    DecisionOut    dec;         /* decision published this tick (Decision.cpp:187-196) */
+    DecisionOutPod dec;         /* decision published this tick (Decision.cpp:187-196) */
     double         ob_dis_lat, ob_dis_lng;   /* SearchObstacle outputs of Planning.cpp:168 */
     ObPoint        ob;
     int32_t        ob_flag, ob_pathid;

@@ -108,7 +108,7 @@ static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v
 
 /* Planning.cpp:303-583.  planning_MapData[road][lane] -> LaneView slices of lane_pool;
  * faraim/nearaim are the members written by Calculate_aim_dis (Planning.cpp:118). */
-void orc_SearchAimPoint(const PlannerConfig* c, const SceneIn* in, const DecisionOut* dec, const GlobalPoint2D* refpath,
+void orc_SearchAimPoint(const PlannerConfig* c, const SceneIn* in, const DecisionOutPod* dec, const GlobalPoint2D* refpath,
                         const GlobalPoint3D* lane_pool, SceneState* st)
 {
     const LocationOut* loc = &in->loc;
@@ -257,7 +257,7 @@ void orc_GetVhclLocalState(const PlannerConfig* c, const LocationOut* loc, const
 }
 
 /* Planning.cpp:797-832 — reads the MEMBERS path_lat_dis/path_dir_err/remain_dis (:810,815,821) */
-int orc_UpdatePlanJudge(const PlannerConfig* c, const DecisionOut* dec, const LocationOut* loc, int last_behavior,
+int orc_UpdatePlanJudge(const PlannerConfig* c, const DecisionOutPod* dec, const LocationOut* loc, int last_behavior,
                         const SceneState* st, int* afreshcause)
 {
     *afreshcause = 0;
@@ -270,7 +270,7 @@ int orc_UpdatePlanJudge(const PlannerConfig* c, const DecisionOut* dec, const Lo
 }
 
 /* Planning.cpp:888-990 — the three cases are identical; other pos values leave the outputs alone */
-void orc_SpeedPlanning(int ob_flag, const DecisionOut* dec, const LocationOut* loc, double mindist_lon, double mindist_lat,
+void orc_SpeedPlanning(int ob_flag, const DecisionOutPod* dec, const LocationOut* loc, double mindist_lon, double mindist_lat,
                        float faraim_dis, double* brake_speed, int* acc_flag, double* des_acc)
 {
     (void)mindist_lat;
@@ -949,6 +949,16 @@ static void orc_StubDecisions(const PlannerConfig* c, const SceneIn* in, const G
 
 /* ------------------------------------------------------------------------------ */
 /* The tick: Decision.cpp:172-205 (decision stage) then Planning.cpp:114-223. */
+/* DecisionOut.refpath of the calling thread's last tick (Decision.cpp:195), for the tests of the refpath hand-off */
+static __thread GlobalPoint2D g_last_refpath[DMPP_MAX_REFPATH];
+static __thread int g_last_refpath_n;
+int orc_last_refpath(GlobalPoint2D* out, int cap)
+{
+    int n = g_last_refpath_n < cap ? g_last_refpath_n : cap;
+    if (n > 0) memcpy(out, g_last_refpath, sizeof(GlobalPoint2D) * (size_t)n);
+    return g_last_refpath_n;
+}
+
 void orc_plan_tick(const PlannerConfig* c, const SceneIn* in, const GlobalPoint3D* lane_pool, const uint8_t* attr_pool,
                    const GlobalPoint2D* ref_pool, const ObPoint* obs_pool, const ObMotion* mot_pool, SceneState* st, PlanOut* po, GridOut* go,
                    uint8_t* grid_scratch, int32_t* order, int order_cap, int32_t* path, int path_cap)
@@ -957,7 +967,7 @@ void orc_plan_tick(const PlannerConfig* c, const SceneIn* in, const GlobalPoint3
     int m = in->obs_n;
     ObPoint* obs = (ObPoint*)malloc(sizeof(ObPoint) * (size_t)(m > 0 ? m : 1));
     DecScratch* d = (DecScratch*)malloc(sizeof(DecScratch));
-    DecisionOut dec;
+    DecisionOutPod dec;
     const GlobalPoint2D* refpath;
 
     memset(po, 0, sizeof(*po));
@@ -989,6 +999,8 @@ void orc_plan_tick(const PlannerConfig* c, const SceneIn* in, const GlobalPoint3
         po->sweep_side = 0; po->sweep_index = -1;
     }
     po->dec = dec;
+    g_last_refpath_n = dec.refpath_n > 0 ? (dec.refpath_n < DMPP_MAX_REFPATH ? dec.refpath_n : DMPP_MAX_REFPATH) : 0;
+    if (g_last_refpath_n) memcpy(g_last_refpath, refpath, sizeof(GlobalPoint2D) * (size_t)g_last_refpath_n);
 
     /* ---- planning tick, Planning.cpp:114-223 ---- */
     GlobalPoint2D road_points[DMPP_PATH_POINTS];

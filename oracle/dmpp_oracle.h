@@ -26,14 +26,15 @@ double orc_GetLatDis(const PlannerConfig*, GlobalPoint2D cur, GlobalPoint2D pt, 
 double orc_GetRoadAngle(const PlannerConfig*, GlobalPoint2D a, GlobalPoint2D b);                       /* Planning.cpp:719-750 */
 double orc_GetAngleErr(double dir1, double dir2);                                                      /* Planning.cpp:760-786 */
 void   orc_Calculate_aim_dis(const PlannerConfig*, const LocationOut*, float* far_, float* near_);     /* Planning.cpp:242-290 */
-void   orc_SearchAimPoint(const PlannerConfig*, const SceneIn*, const DecisionOut*, const GlobalPoint2D* refpath,
+int    orc_last_refpath(GlobalPoint2D* out, int cap);   /* refpath published by this thread's last orc_plan_tick; returns its length */
+void   orc_SearchAimPoint(const PlannerConfig*, const SceneIn*, const DecisionOutPod*, const GlobalPoint2D* refpath,
                           const GlobalPoint3D* lane_pool, SceneState*);                                /* Planning.cpp:303-583 */
 void   orc_GetVhclLocalState(const PlannerConfig*, const LocationOut*, const GlobalPoint2D last_Bpoints[DMPP_PATH_POINTS],
                              double* mindist_lat, double* path_dir_err, int* mindist_id, int* front_mindist_id,
                              double* remain_dis);                                                      /* Planning.cpp:623-676 */
-int    orc_UpdatePlanJudge(const PlannerConfig*, const DecisionOut*, const LocationOut*, int last_behavior,
+int    orc_UpdatePlanJudge(const PlannerConfig*, const DecisionOutPod*, const LocationOut*, int last_behavior,
                            const SceneState*, int* afreshcause);                                       /* Planning.cpp:797-832 */
-void   orc_SpeedPlanning(int ob_flag, const DecisionOut*, const LocationOut*, double mindist_lon, double mindist_lat,
+void   orc_SpeedPlanning(int ob_flag, const DecisionOutPod*, const LocationOut*, double mindist_lon, double mindist_lat,
                          float faraim_dis, double* brake_speed, int* acc_flag, double* des_acc);       /* Planning.cpp:888-990 */
 double orc_CalculateRadius(const GlobalPoint2D last_Bpoints[DMPP_PATH_POINTS], int near_id, int front_id); /* Planning.cpp:1000-1019 */
 

@@ -54,6 +54,7 @@ class Oracle:
         L.orc_plan_tick.argtypes = [vp] * 10 + [vp, vp, ci, vp, ci]
         L.orc_plan_tick_batch.argtypes = [vp, ci] + [vp] * 10 + [ci]
         L.orc_plan_ticks_batch.argtypes = [vp, ci] + [vp] * 10 + [ci, ci]
+        L.orc_last_refpath.argtypes = [vp, ci]
 
     # ---- scalar helpers ----
     def GetLatDis(self, cfg, cur, pt, nxt):
@@ -142,6 +143,12 @@ class Oracle:
         self.L.orc_plan_ticks_batch(_p(cfg), n, _p(sc["scene_in"]), _p(sc["lane_pool"]), _p(sc.get("attr_pool")), _p(sc["ref_pool"]),
                                     _p(sc["obs_pool"]), _p(sc["mot_pool"]), _p(state), _p(plan), _p(gout), _p(grids), n_threads, n_ticks)
         return plan, gout, grids
+
+    def last_refpath(self):
+        """DecisionOut.refpath of the last plan_tick_one on this thread."""
+        out = np.zeros(dm.MAX_REFPATH, dm.GlobalPoint2D)
+        n = self.L.orc_last_refpath(_p(out), len(out))
+        return out[:n]
 
     def plan_tick_one(self, cfg, sc, s, state, order_cap=0):
         """One scene with expansion order and path kept."""

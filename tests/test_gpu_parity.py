@@ -272,7 +272,7 @@ def test_scalar_stage_ops(dm, oracle):
     cfg = dm.default_config(128)
     pl = dm.Planner(cfg, max_scenes=1)
     rng = np.random.default_rng(4)
-    dec, loc, st = np.zeros(1, dm.DecisionOut), np.zeros(1, dm.LocationOut), np.zeros(1, dm.SceneState)
+    dec, loc, st = np.zeros(1, dm.DecisionOutPod), np.zeros(1, dm.LocationOut), np.zeros(1, dm.SceneState)
     for _ in range(60):
         hb, b, pos = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(0, 4))
         lat, derr, rem = float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-90, 90)), float(rng.uniform(0, 20))

@@ -75,7 +75,7 @@ def test_CalculateRadius(oracle, dm):                   # Planning.cpp:1000-1019
 
 
 def test_SpeedPlanning_branches(oracle, dm):            # Planning.cpp:888-990
-    dec, loc = np.zeros(1, dm.DecisionOut), np.zeros(1, dm.LocationOut)
+    dec, loc = np.zeros(1, dm.DecisionOutPod), np.zeros(1, dm.LocationOut)
     dec["velocity_expect"] = 10.0
     S = lambda flag, lon, far=30.0: oracle.SpeedPlanning(flag, dec, loc, lon, 0.0, far)
     assert S(0, 999.0) == (10.0, 0, 0.0)                                  # no obstacle -> expected speed

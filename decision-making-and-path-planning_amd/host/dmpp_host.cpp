@@ -58,6 +58,11 @@ int run_scene(OneScene& s, SceneState& st, PlanOut& out, GridOut* grid, bool dec
     int rc = PP_OK;
     if (!have_applied || std::memcmp(&applied, &c, sizeof(c)) != 0) {
         rc = pp_set_config(h, &c);
+        if (rc == PP_ERR_CAPACITY) {                       // a larger grid than the handle was made for: make a new one
+            CShare::Recreate();
+            h = CShare::Device();
+            rc = h ? pp_set_config(h, &c) : PP_ERR_HIP;
+        }
         if (rc) { have_applied = false; return rc; }
         applied = c; have_applied = true;
     }
@@ -80,9 +85,15 @@ pp_handle CShare::Device()
         PlannerCaps caps{};
         caps.max_scenes = 1; caps.max_obs_total = 4096; caps.max_lane_pts_total = 1 << 16; caps.max_ref_pts_total = DMPP_MAX_REFPATH;
         const char* dv = std::getenv("DMPP_DEVICE");
-        note(pp_create(&Config(), dv ? std::atoi(dv) : 0, &caps, &g_handle));
+        PlannerConfig c = Config();
+        c.grid_stage = 1;                                  // buffers of the grid stage exist whether or not the first call uses it
+        note(pp_create(&c, dv ? std::atoi(dv) : 0, &caps, &g_handle));
     }
     return g_handle;
+}
+void CShare::Recreate()
+{
+    if (g_handle) { pp_destroy(g_handle); g_handle = nullptr; }
 }
 void CShare::BezierPlanning(GlobalPoint3D start, GlobalPoint3D end, GlobalPoint2D out[], int n)
 { note(pp_bezier(Device(), start, end, out, n)); }

@@ -50,6 +50,7 @@ class CShare {
 public:
     // one GPU context per process for the single-scene class surface (device: env DMPP_DEVICE, default 0)
     static pp_handle Device();
+    static void Recreate();          // drops the context; the next Device() makes one for the current Config() (a larger grid)
     static PlannerConfig& Config();
     static DmppStatus& LastStatus();
 

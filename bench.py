@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-GRID_KERNELS = ("k_effective_obstacles", "k_rasterise", "k_order", "k_search", "k_score")
+GRID_KERNELS = ("k_effective_obstacles", "k_rasterise", "k_order", "k_search", "k_search_fallback", "k_score")
 
 
 def parse():
@@ -96,6 +96,7 @@ def algorithmic_bytes(cfg, n_obs):
         "k_rasterise": W * H + 24 * n_obs,           # one write per cell (the device writes it bit-packed, twice: W*H/4 bytes)
         "k_search": W * H + 3200,                    # one read per cell + the path out (read bit-packed: W*H/4 bytes)
         "k_score": 24 * n_obs + 3200 + 3200,
+        "k_search_fallback": W * H + 3200,
     }
     return b_r, b_g, per_kernel
 

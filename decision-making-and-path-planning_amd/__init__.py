@@ -20,7 +20,7 @@ GEN_LANE_PTS, GEN_REF_PTS = 320, 128
 
 G_FOUND, G_NO_PATH, G_LIMIT, G_OVERFLOW, G_GOAL_BLOCKED, G_PATH_TRUNC, G_INTERNAL, G_COST_RANGE = range(8)
 G_STATUS_COUNT = 8
-K_NAMES = ["k_effective_obstacles", "k_decision", "k_planning", "k_rasterise", "k_search", "k_score"]
+K_NAMES = ["k_effective_obstacles", "k_decision", "k_planning", "k_rasterise", "k_search", "k_score", "k_search_fallback"]
 (BUF_SCENE_IN, BUF_LANE_POOL, BUF_REF_POOL, BUF_OBS_POOL, BUF_MOT_POOL, BUF_STATE, BUF_PLAN_OUT, BUF_GRID_OUT,
  BUF_GRID, BUF_PATH, BUF_ORDER, BUF_LANE_ATTR) = range(12)
 

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <vector>
 #include <new>
+#include <algorithm>
 #include "../../include/dmpp_planner.h"
 #include "kernels_r.hpp"
 #include "kernels_g.hpp"
@@ -55,7 +56,13 @@ struct pp_planner {
     hipStream_t stream_m2 = nullptr; int n_obs_total = 0; int overlap_override = -1;
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
-    bool search_gbm = false; int search_lds = 0; int raster_band_rows = 0; bool raster_band_fixed = false;
+    // search: k_search_lds<kind> with `lds_budget` data words per view in LDS; scenes that need more go to k_search_gbm
+    int search_kind = 0; int search_meta_bytes = 0; int lds_budget = 0, lds_budget_max = 0; bool lds_budget_fixed = false, search_force_gbm = false;
+    int gbm_lds = 0; int search_slots = 512;
+    int32_t* d_ovf[2] = { nullptr, nullptr }; int32_t* d_need[2] = { nullptr, nullptr }; int32_t* h_need = nullptr;   // h_need: pinned, [2]
+    hipEvent_t ev_need[2] = { nullptr, nullptr }; bool need_pending[2] = { false, false }; int need_seen = 0;
+    int* d_gridbad = nullptr;
+    int raster_band_rows = 0; bool raster_band_fixed = false;
     hipStream_t stream_r = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the R kernels run beside the grid engine
     // k_score of tick t runs on its own stream beside the rasterise / search of tick t+1: the obstacle snapshot, the path
     // cells and GridOut are double-buffered by tick parity; ev_score[p] = the last k_score that used the buffers p
@@ -63,6 +70,7 @@ struct pp_planner {
     hipEvent_t ev_raster = nullptr;
     bool score_recorded[2] = { false, false }, search_recorded[2] = { false, false }, front_recorded = false, front_unjoined = false;
     int parity = 0;              // buffers of the last tick
+    int n_cus = 256;
     int pipeline_min = 256;      // batches at least this large run the three chains on three streams (env DMPP_PIPELINE_MIN)
     bool r_on_main = false;      // the last tick ran Decision + Planning on the handle's stream (grid stage off)
     int n_lane_pts = 0, n_ref_pts = 0;   // pool sizes of the resident scenes (slice validation)
@@ -111,7 +119,6 @@ hipEvent_t get_event(pp_planner* h)
 }
 
 constexpr int kScoreWideMaxScenes = 128;     // up to here k_score runs 16 waves per scene (one scene per CU at most)
-constexpr int kSearchSlots = 512;            // search waves resident at once on 256 CUs (80 KB of LDS each)
 
 // Everything the ticks enqueued so far started - on any of the four streams - is ordered before whatever the handle's
 // stream does next: ev_score[q] closes the raster -> search -> score chain of the last tick of parity q, ev_join the
@@ -175,31 +182,54 @@ int setup_grid_launch(pp_planner* h)
         if (lds + 12288 > 48u * 1024u)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_rasterise), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    // search: word summaries of both bitmap views always in LDS; the bitmaps too when they fit, else in HBM
-    const size_t bm_bytes = 2 * (N / 8);              // row-major + column-major obstacle bits
-    const size_t ww = (size_t)c.grid_w / 32, hw = (size_t)c.grid_h / 32;
-    const size_t nz_bytes = 4 * ((size_t)c.grid_h * ((ww + 31) / 32) + (size_t)c.grid_w * ((hw + 31) / 32));
-    const size_t static_lds = 12288;                  // open list, closed hash, small tables (k_search's __shared__ arrays: 11.9 KB)
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
-    size_t lds_max = prop.sharedMemPerBlock;          // 64 KiB default, 160 KiB opt-in on gfx950
+    // search: per-line metas of both sparse views + the budgeted data words in dynamic LDS (kernels_s.hpp)
+    const int lw = (int)std::max((size_t)c.grid_w / 32, (size_t)c.grid_h / 32);
+    h->search_kind = lw <= 16 ? 0 : (lw <= 32 ? 1 : 2);
+    const size_t per_line = h->search_kind == 0 ? 4 : (h->search_kind == 1 ? 8 : 12);
+    h->search_meta_bytes = (int)((((size_t)c.grid_w + c.grid_h) * per_line + 15) & ~(size_t)15);
+    const size_t static_lds = sizeof(dmpp::SearchLds) + 64;
+    size_t lds_max = 64u * 1024u;
     {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && (size_t)v > lds_max) lds_max = (size_t)v;
     }
     if (lds_max > 160u * 1024u) lds_max = 160u * 1024u;
-    if (nz_bytes + static_lds > lds_max) return fail(PP_ERR_CAPACITY, "grid too large for the search kernel's LDS tables");
-    h->search_gbm = bm_bytes + nz_bytes + static_lds > lds_max;
-    h->search_lds = (int)(nz_bytes + (h->search_gbm ? 0 : bm_bytes));
-    if ((size_t)h->search_lds + static_lds > 48u * 1024u) {
-        const void* fn = h->search_gbm ? reinterpret_cast<const void*>(&dmpp::k_search<true>) : reinterpret_cast<const void*>(&dmpp::k_search<false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, h->search_lds);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            if (h->search_gbm) return fail(PP_ERR_HIP, "cannot reserve LDS for the search kernel");
-            h->search_gbm = true; h->search_lds = (int)nz_bytes;
+    h->gbm_lds = (int)(((size_t)c.grid_w + c.grid_h) * 8);
+    if ((size_t)h->search_meta_bytes + static_lds + 2 * 64 * 4 > lds_max || (size_t)h->gbm_lds + static_lds > lds_max)
+        return fail(PP_ERR_CAPACITY, "grid too large for the search kernel's LDS tables");
+    {
+        const size_t room = (lds_max - static_lds - (size_t)h->search_meta_bytes) / 8;        // data words per view that fit at all
+        const size_t dense = N / 32;                                                            // ... that a view can ever need
+        h->lds_budget_max = (int)std::min(room, dense);
+        const void* fns[3] = { reinterpret_cast<const void*>(&dmpp::k_search_lds<0>), reinterpret_cast<const void*>(&dmpp::k_search_lds<1>),
+                               reinterpret_cast<const void*>(&dmpp::k_search_lds<2>) };
+        const void* fne[3] = { reinterpret_cast<const void*>(&dmpp::k_export_grid<0>), reinterpret_cast<const void*>(&dmpp::k_export_grid<1>),
+                               reinterpret_cast<const void*>(&dmpp::k_export_grid<2>) };
+        const int dyn_max = h->search_meta_bytes + 8 * h->lds_budget_max;
+        if (dyn_max + (int)static_lds > 48 * 1024) {
+            if (hipFuncSetAttribute(fns[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess ||
+                hipFuncSetAttribute(fne[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess) {
+                (void)hipGetLastError();
+                h->lds_budget_max = (int)std::min((size_t)h->lds_budget_max, (48u * 1024u - static_lds - (size_t)h->search_meta_bytes) / 8);
+            }
         }
+        if ((size_t)h->gbm_lds + static_lds > 48u * 1024u)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_search_gbm), hipFuncAttributeMaxDynamicSharedMemorySize, h->gbm_lds));
     }
+    if (const char* e = std::getenv("DMPP_SEARCH_GBM")) h->search_force_gbm = std::atoi(e) != 0;          // test / measurement knob: dense bitmaps in HBM for every scene
+    if (const char* e = std::getenv("DMPP_LDS_BUDGET")) {                                                // ... a fixed budget (words per view)
+        h->lds_budget = std::max(1, std::min(std::atoi(e), h->lds_budget_max)); h->lds_budget_fixed = true;
+    } else h->lds_budget = 0;                                                                            // chosen at the first tick (obstacle density), then adaptive
+    for (int q = 0; q < 2; q++) {
+        if (!h->d_ovf[q]) {
+            int r = dmalloc(&h->d_ovf[q], (size_t)h->caps.max_scenes); if (r) return r;
+            HIP_TRY(hipMemsetAsync(h->d_ovf[q], 0, (size_t)h->caps.max_scenes * sizeof(int32_t), h->stream));
+        }
+        if (!h->d_need[q]) { int r = dmalloc(&h->d_need[q], (size_t)1); if (r) return r; }
+        if (!h->ev_need[q]) HIP_TRY(hipEventCreateWithFlags(&h->ev_need[q], hipEventDisableTiming));
+    }
+    if (!h->h_need) { HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_need), 2 * sizeof(int32_t), hipHostMallocDefault)); h->h_need[0] = h->h_need[1] = 0; }
+    if (!h->d_gridbad) { int r = dmalloc(&h->d_gridbad, (size_t)2); if (r) return r; }
     if (sizeof(dmpp::ScoreShared<16>) > 48u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_score<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(dmpp::ScoreShared<16>));
     for (int q = 0; q < 2; q++) {
@@ -251,7 +281,7 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     int side_cus = 0;
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess) side_cus = prop.multiProcessorCount * 88 / 100;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) { side_cus = prop.multiProcessorCount * 88 / 100; h->n_cus = prop.multiProcessorCount; }
         if (const char* e = std::getenv("DMPP_SIDE_CUS")) side_cus = std::atoi(e);
     }
     uint32_t cu_mask[32] = { 0 };
@@ -319,10 +349,13 @@ int pp_destroy(pp_handle h)
     void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now[0], h->d_obs_now[1], h->d_state, h->d_plan,
                      h->d_gout[0], h->d_gout[1], h->d_dec_ref, h->d_grid, h->d_pinfo[0], h->d_pinfo[1], h->d_closed[0], h->d_closed[1],
                      h->d_order[0], h->d_order[1], h->d_path[0], h->d_path[1], h->d_gbm[0], h->d_gbm[1], h->d_perm[0], h->d_perm[1],
-                     h->d_cost[0], h->d_cost[1], h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad, h->d_bad };
+                     h->d_cost[0], h->d_cost[1], h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad, h->d_bad,
+                     h->d_ovf[0], h->d_ovf[1], h->d_need[0], h->d_need[1], h->d_gridbad };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int q = 0; q < 2; q++) { if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]); if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]); }
     if (h->ev_raster) (void)hipEventDestroy(h->ev_raster);
+    for (int q = 0; q < 2; q++) if (h->ev_need[q]) (void)hipEventDestroy(h->ev_need[q]);
+    if (h->h_need) (void)hipHostFree(h->h_need);
     if (h->stream_s) (void)hipStreamDestroy(h->stream_s);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -517,16 +550,43 @@ int pp_plan_tick(pp_handle h)
     const PlannerConfig& c = h->cfg;
     if (c.decision_stage && c.lanechg_stage && !h->have_attr)
         return fail(PP_ERR_ARG, "cfg.lanechg_stage needs the lane attribute pool (pp_set_scenes lane_attr_pool)");
-    // One tick = three chains.  FRONT (stream_r): obstacle snapshot, rasterise, Decision, Planning - short kernels;
-    // SEARCH (the handle's stream): k_order + k_search, the long one; SCORE (stream_s): k_score.  The obstacle snapshot,
-    // the bitmaps, the path cells and GridOut alternate between two buffers by tick parity, so the front of tick t+1
-    // and the score of tick t both run beside the search (which leaves most CUs idle in its tail):
-    //   front(t)  waits for score(t-2) [snapshot p] and search(t-2) [bitmaps p];
-    //   search(t) waits for rasterise(t) and score(t-2) [path / GridOut p];  score(t) waits for search(t).
+    // One tick = three chains.  FRONT (stream_r): obstacle snapshot, (launch order), Decision, Planning - short kernels;
+    // SEARCH (the handle's stream): k_search_lds (+ the dense fallback for scenes it hands on), the long one; SCORE
+    // (stream_s): k_score.  The obstacle snapshot, the path cells and GridOut alternate between two buffers by tick
+    // parity, so the front of tick t+1 and the score of tick t both run beside the search:
+    //   front(t)  waits for search(t-2) and score(t-2) [both read the snapshot p];
+    //   search(t) waits for the snapshot of front(t) and for score(t-2) [path / GridOut p];  score(t) waits for search(t).
     // Small batches and ticks without the grid stage stay on one stream (a cross-stream hand-over costs tens of
     // microseconds; only Decision + Planning run beside the grid engine there).
     const int p = h->parity ^ 1;
     const bool piped = c.grid_stage && n >= h->pipeline_min;
+    if (c.grid_stage && !h->search_force_gbm) {
+        // LDS budget of the search (data words per view).  First tick: from the obstacle density; afterwards from what the
+        // densest scene of an earlier tick needed (+ 1/8), read from pinned memory once its copy has landed - never waited for.
+        if (!h->lds_budget_fixed) {
+            int need = -1;
+            for (int q = 0; q < 2; q++)
+                if (h->need_pending[q] && hipEventQuery(h->ev_need[q]) == hipSuccess) { h->need_pending[q] = false; need = std::max(need, (int)h->h_need[q]); }
+            (void)hipGetLastError();               // hipEventQuery's "not ready" is not an error
+            int want = h->lds_budget;
+            if (need >= 0) {
+                h->need_seen = need;
+                const int fit = std::min(h->lds_budget_max, (need + need / 8 + 64 + 63) / 64 * 64);
+                if (fit > h->lds_budget || fit < h->lds_budget - h->lds_budget / 4) want = fit;      // grow at once, shrink with hysteresis
+            }
+            if (want <= 0) {
+                const long long per_scene = ((long long)h->n_obs_total + n - 1) / n;
+                want = (int)std::min<long long>(h->lds_budget_max, (28 * per_scene + 256 + 63) / 64 * 64);
+            }
+            h->lds_budget = std::max(64, std::min(want, h->lds_budget_max));
+        }
+        const size_t per_wg = sizeof(dmpp::SearchLds) + 64 + (size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / per_wg));       // 4 waves per workgroup while it sets up: <= 8 per CU
+        h->search_slots = per_cu * std::max(1, h->n_cus);
+    } else if (c.grid_stage) {
+        const size_t per_wg = sizeof(dmpp::SearchLds) + 64 + (size_t)h->gbm_lds;
+        h->search_slots = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / per_wg)) * std::max(1, h->n_cus);
+    }
     // consecutive searches overlap when a search is long next to the front chain (Decision, Planning and the rasteriser share
     // one stream and bound the tick from below): many obstacles per scene, or grids beyond 512 x 512.  Measured: 256 obstacles
     // +40 %, 2048 x 2048 +7 %, but -8 % on 64 obstacles at 512 x 512, where the front chain is as long as the search.
@@ -552,23 +612,13 @@ int pp_plan_tick(pp_handle h)
                            h->d_obs, h->have_motion ? h->d_mot : nullptr, obs_now);
     }
     if (sr != sf) { HIP_TRY(hipEventRecord(h->ev_fork, sf)); HIP_TRY(hipStreamWaitEvent(sr, h->ev_fork, 0)); }   // small batches: Decision + Planning beside the grid engine
-    if (c.grid_stage) {
-        Timed t(h, PP_K_RASTERISE, sf);
-        // a handful of scenes does not fill the chip with 128-row bands: halve the bands (down to 32 rows) until there are
-        // some 512 workgroups - one scene at 512 x 512: 16 us -> 10 us of the latency-bound tick
-        const int band_rows = h->raster_band_fixed ? h->raster_band_rows : raster_band_rows_for(c.grid_h, n, h->raster_band_rows);
-        const int bands = (c.grid_h + band_rows - 1) / band_rows;
-        const size_t lds = 2 * ((size_t)band_rows * c.grid_w / 8);                // the band row-major and column-major
-        hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), lds, sf, c, n, band_rows,
-                           h->d_in, obs_now, h->d_gbm[p]);
-    }
-    // launch order of the search (heaviest scenes first) - pointless while every scene is resident at once (2 per CU).
+    // launch order of the search (heaviest scenes first) - pointless while every scene is resident at once.
     // In the three-chain tick it is computed here, on the front chain, from the search of tick t-2 (certainly complete:
     // this chain has waited for it), so that nothing stands between two consecutive searches on their stream.
-    const bool order_scenes = c.grid_stage && n > kSearchSlots;
+    const bool order_scenes = c.grid_stage && n > h->search_slots;
     const bool order_in_front = order_scenes && piped;
     if (order_in_front) hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sf, n, h->d_cost[p], h->d_perm[p]);
-    if (sf != sm) HIP_TRY(hipEventRecord(h->ev_raster, sf));
+    if (sf != sm) HIP_TRY(hipEventRecord(h->ev_raster, sf));        // the search rasterises for itself: it only needs the obstacle snapshot (and its launch order)
     if (c.decision_stage) {
         Timed t(h, PP_K_DECISION, sr);
         hipLaunchKernelGGL(dmpp::k_decision, dim3(n), dim3(dmpp::kBlock), sizeof(dmpp::DecShared), sr, c, n, h->d_in, h->d_lane,
@@ -582,17 +632,45 @@ int pp_plan_tick(pp_handle h)
     if (sr != h->stream) { HIP_TRY(hipEventRecord(h->ev_join, sr)); h->front_recorded = true; h->front_unjoined = piped; }
     if (c.grid_stage) {
         if (sf != sm) HIP_TRY(hipStreamWaitEvent(sm, h->ev_raster, 0));
-        {
-            Timed t(h, PP_K_SEARCH, sm);
-            const int32_t* perm = order_scenes ? h->d_perm[p] : nullptr;
-            if (perm && !order_in_front)          // one-stream tick with more scenes than search slots (DMPP_PIPELINE_MIN raised): keyed by the previous tick
-                hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[p ^ 1], h->d_perm[p]);
-            if (h->search_gbm)
-                hipLaunchKernelGGL(dmpp::k_search<true>, dim3(n), dim3(dmpp::kSearchBlock), (size_t)h->search_lds, sm, c, n, h->caps.order_cap, perm, h->d_in,
-                                   h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost[p]);
-            else
-                hipLaunchKernelGGL(dmpp::k_search<false>, dim3(n), dim3(dmpp::kSearchBlock), (size_t)h->search_lds, sm, c, n, h->caps.order_cap,
-                                   perm, h->d_in, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost[p]);
+        const int32_t* perm = order_scenes ? h->d_perm[p] : nullptr;
+        if (perm && !order_in_front)          // one-stream tick with more scenes than search slots (DMPP_PIPELINE_MIN raised): keyed by the previous tick
+            hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[p ^ 1], h->d_perm[p]);
+        const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
+        const size_t raster_lds = 2 * ((size_t)h->raster_band_rows * c.grid_w / 8);
+        if (h->search_force_gbm) {            // measurement / test knob: every scene on dense bitmaps in HBM
+            Timed t(h, PP_K_FALLBACK, sm);
+            hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), raster_lds, sm, c, n, h->raster_band_rows,
+                               h->d_in, obs_now, h->d_gbm[p], (const int32_t*)nullptr, 0);
+            hipLaunchKernelGGL(dmpp::k_search_gbm, dim3(n), dim3(dmpp::kSearchBlock), (size_t)h->gbm_lds, sm, c, n, h->caps.order_cap, (const int32_t*)nullptr,
+                               h->d_in, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost[p]);
+        } else {
+            HIP_TRY(hipMemsetAsync(h->d_need[p], 0, sizeof(int32_t), sm));
+            const size_t dyn = (size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget;
+            {
+                Timed t(h, PP_K_SEARCH, sm);
+                switch (h->search_kind) {
+#define DMPP_LAUNCH_LDS(K)                                                                                                                       \
+                case K: hipLaunchKernelGGL(dmpp::k_search_lds<K>, dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, h->lds_budget, \
+                                           perm, h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p],        \
+                                           h->d_cost[p], h->d_ovf[p], h->d_need[p]); break;
+                DMPP_LAUNCH_LDS(0) DMPP_LAUNCH_LDS(1) DMPP_LAUNCH_LDS(2)
+#undef DMPP_LAUNCH_LDS
+                }
+            }
+            {   // scenes whose obstacle words did not fit the budget (flagged by the kernel above; none in the steady state, and then
+                // both kernels below return at once): dense bitmaps through HBM
+                Timed t(h, PP_K_FALLBACK, sm);
+                hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), raster_lds, sm, c, n, h->raster_band_rows,
+                                   h->d_in, obs_now, h->d_gbm[p], (const int32_t*)h->d_ovf[p], 0);
+                hipLaunchKernelGGL(dmpp::k_search_gbm, dim3(n), dim3(dmpp::kSearchBlock), (size_t)h->gbm_lds, sm, c, n, h->caps.order_cap,
+                                   (const int32_t*)h->d_ovf[p], h->d_in, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p],
+                                   h->d_gbm[p], h->d_cost[p]);
+            }
+            if (!h->lds_budget_fixed) {       // the words the densest scene needed, for the budget of later ticks (read without waiting)
+                HIP_TRY(hipMemcpyAsync(&h->h_need[p], h->d_need[p], sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+                HIP_TRY(hipEventRecord(h->ev_need[p], sm));
+                h->need_pending[p] = true;
+            }
         }
         h->search_recorded[p] = piped;                   // (one-stream mode: stream order is enough, no events on the latency path)
         if (piped) { HIP_TRY(hipEventRecord(h->ev_search[p], sm)); HIP_TRY(hipStreamWaitEvent(ss, h->ev_search[p], 0)); }
@@ -661,13 +739,38 @@ int pp_get_grid(pp_handle h, int scene, uint8_t* grid)
 {
     if (!h || !grid || !h->d_grid) return fail(PP_ERR_ARG, "no grid");
     if (scene < 0 || scene >= h->n_scenes) return fail(PP_ERR_ARG, "scene out of range");
-    const size_t N = (size_t)h->cfg.grid_w * h->cfg.grid_h;
-    // the tick keeps the grid bit-packed; its byte form is produced here, for the one scene asked for
+    const PlannerConfig& c = h->cfg;
+    const size_t N = (size_t)c.grid_w * c.grid_h;
+    // No occupancy grid exists after a tick: the search builds its sparse bitmaps in LDS and drops them.  The grid asked for is
+    // produced here, from the obstacle snapshot of the last tick, by the same footprint code (k_export_grid), which also checks
+    // the column-major view against the row-major one.  A scene too dense for one workgroup's LDS goes through k_rasterise.
     HIP_TRY(hipSetDevice(h->device));
-    { int r = join_all(h); if (r) return r; }       // the rasteriser of the last tick ran on another stream
-    hipLaunchKernelGGL(dmpp::k_expand_grid, dim3((unsigned)((N / 16 + dmpp::kRasterBlock - 1) / dmpp::kRasterBlock)), dim3(dmpp::kRasterBlock), 0,
-                       h->stream, h->cfg.grid_w, h->cfg.grid_h, h->d_gbm[h->parity] + (size_t)scene * 2 * (N / 32), h->d_grid);
-    HIP_TRY(hipGetLastError());
+    { int r = join_all(h); if (r) return r; }       // the snapshot of the last tick was written on another stream
+    const ObPoint* obs_now = h->d_obs_now[h->parity];
+    int bad[2] = { 0, 1 };
+    if (!h->search_force_gbm) {
+        HIP_TRY(hipMemsetAsync(h->d_gridbad, 0, 2 * sizeof(int), h->stream));
+        const size_t dyn = (size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget_max;
+        switch (h->search_kind) {
+        case 0: hipLaunchKernelGGL(dmpp::k_export_grid<0>, dim3(1), dim3(dmpp::kSearchBlock), dyn, h->stream, c, scene, h->lds_budget_max, h->d_in, obs_now, h->d_grid, h->d_gridbad); break;
+        case 1: hipLaunchKernelGGL(dmpp::k_export_grid<1>, dim3(1), dim3(dmpp::kSearchBlock), dyn, h->stream, c, scene, h->lds_budget_max, h->d_in, obs_now, h->d_grid, h->d_gridbad); break;
+        default: hipLaunchKernelGGL(dmpp::k_export_grid<2>, dim3(1), dim3(dmpp::kSearchBlock), dyn, h->stream, c, scene, h->lds_budget_max, h->d_in, obs_now, h->d_grid, h->d_gridbad); break;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(bad, h->d_gridbad, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (bad[0]) return fail(PP_ERR_STATE, "pp_get_grid: the row-major and column-major views of the scene differ in " + std::to_string(bad[0]) + " cell(s)");
+    }
+    if (bad[1]) {
+        const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
+        const size_t lds = 2 * ((size_t)h->raster_band_rows * c.grid_w / 8);
+        uint32_t* gb = h->d_gbm[h->parity];
+        hipLaunchKernelGGL(dmpp::k_rasterise, dim3(1, bands), dim3(dmpp::kRasterBlock), lds, h->stream, c, h->n_scenes, h->raster_band_rows,
+                           h->d_in, obs_now, gb, (const int32_t*)nullptr, scene);
+        hipLaunchKernelGGL(dmpp::k_expand_grid, dim3((unsigned)((N / 16 + dmpp::kRasterBlock - 1) / dmpp::kRasterBlock)), dim3(dmpp::kRasterBlock), 0,
+                           h->stream, c.grid_w, c.grid_h, gb + (size_t)scene * 2 * (N / 32), h->d_grid);
+        HIP_TRY(hipGetLastError());
+    }
     return fetch(h, grid, h->d_grid, N);
 }
 int pp_get_order(pp_handle h, int scene, int32_t* order, int cap)
@@ -949,7 +1052,7 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes)
     case PP_BUF_STATE: p = h->d_state; b = ns * sizeof(SceneState); break;
     case PP_BUF_PLAN_OUT: p = h->d_plan; b = ns * sizeof(PlanOut); break;
     case PP_BUF_GRID_OUT: p = h->d_gout[h->parity]; b = ns * sizeof(GridOut); break;      // the buffers of the last tick
-    case PP_BUF_GRID: p = h->d_gbm[h->parity]; b = ns * 2 * (h->grid_cells / 8); break;      // bit-packed: per scene row-major then column-major
+    case PP_BUF_GRID: p = nullptr; b = 0; break;      // no occupancy grid is kept after a tick (the search builds it in LDS): use pp_get_grid
     case PP_BUF_PATH: p = h->d_path[h->parity]; b = ns * (size_t)h->max_path0 * 4; break;
     case PP_BUF_LANE_ATTR: p = h->d_attr; b = (size_t)h->caps.max_lane_pts_total; break;
     case PP_BUF_ORDER: p = h->d_order[h->parity]; b = ns * (size_t)h->caps.order_cap * 4; break;

@@ -1,0 +1,1043 @@
+// kernels_s.hpp — G2, the jump-point A* of the grid engine (specification: oracle/dmpp_grid_oracle.c, DESIGN.md §5;
+// the reference has no grid code).  ONE searching wave per scene.
+//
+//   k_search_lds<K> : the scene's workgroup (4 waves) rasterises its own obstacle list straight into LDS as a SPARSE
+//                     two-view bitmap - row-major for E/W scans, column-major for N/S scans; per line a mask of the
+//                     words that hold an obstacle bit and the index of the line's first stored word (per-line CSR);
+//                     only non-zero words are stored.  No occupancy grid crosses HBM on this path, and a scene needs
+//                     ~12 KB (64 obstacles) instead of 64 KB of bitmaps, whatever the grid size.  Then wave 0 searches.
+//   k_search_gbm    : the same search on a dense bitmap in HBM (written by k_rasterise) with the line masks in LDS -
+//                     only for scenes whose non-zero words do not fit the launch's LDS budget (flagged by k_search_lds).
+//
+// The search loop (search_core) is shared:
+//   * a straight jump is ONE lane (jump_lane): it visits, in travel order, only the words where the line or one of its
+//     two neighbours has an obstacle bit (or the goal) and builds  blocked | forced | goal  with two shifts;
+//   * a diagonal jump (<= DMPP_DIAG_JUMP cells) is a group of 16 lanes: lane pair k scans horizontally | vertically from
+//     cell k+1 of the diagonal; the pair of cell 8 is free for the straight successors, so one round serves a step;
+//   * a step takes up to 4 open entries of the minimal f (their g is final, so the search stays optimal), closes them
+//     and expands them on 4 x 8 lanes (node x direction);
+//   * the open list lives in LDS in push order (f/2, x|y|dir, run): minimum by DPP wave reduction, ties picked with
+//     ballots, dead slots squeezed out with ballot + prefix-popcount compaction;
+//   * closed cells: an LDS hash (atomicCAS insertion, direction + run length beside the cell).  A scene that outgrows it
+//     (> 768 closed cells) spills: it zeroes its bit set in HBM only then, replays the hash into it and goes on there.
+#pragma once
+#include <type_traits>
+#include "dev_geom.hpp"
+
+namespace dmpp {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t v)
+{
+    uint64_t z = v + 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ int cell_of(const PlannerConfig& c, GlobalPoint2D origin, double x, double y)
+{
+    int ix = (int)floor((x - origin.x) / c.cell);
+    int iy = (int)floor((y - origin.y) / c.cell);
+    ix = clampi(ix, 0, c.grid_w - 1); iy = clampi(iy, 0, c.grid_h - 1);
+    return iy * c.grid_w + ix;
+}
+
+__device__ __forceinline__ int hfun(int x, int y, int gx, int gy)
+{
+    int dx = abs(x - gx), dy = abs(y - gy);
+    return 10 * max(dx, dy) + 4 * min(dx, dy);
+}
+
+constexpr int kOpenCap = DMPP_OPEN_CAP;
+constexpr int kClosedLog = 10, kClosedTab = 1 << kClosedLog, kClosedMax = 768;      // LDS closed-set hash; beyond kClosedMax the scene spills to HBM
+constexpr int kDiagK = DMPP_DIAG_JUMP;                  // cells a diagonal jump looks ahead
+constexpr int kDiagGroup = 2 * kDiagK;                  // lanes per diagonal jump: (cell, horizontal | vertical component)
+constexpr int kDiagPerRound = DMPP_WAVE / kDiagGroup;
+constexpr int kMaxDiag = 16;                            // diagonal jumps of a step: <= 4 nodes x 4 (start) / x 3
+constexpr int kSearchSetupWaves = 4, kSearchBlock = kSearchSetupWaves * DMPP_WAVE;
+constexpr int kOrderShift = 13;                         // search-time classes of 8 Ki cycles (k_order)
+constexpr int kOrderClasses = 1024;
+
+// minimum over the 64 lanes, returned in every lane: DPP prefix-min inside each row of 16 lanes
+// (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row results to lane 63.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#define DMPP_DPP_MIN(ctrl, rowmask)                                                                              \
+    { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, ctrl, rowmask, 0xf, false); \
+      v = t < v ? t : v; }
+    DMPP_DPP_MIN(0x111, 0xf) DMPP_DPP_MIN(0x112, 0xf) DMPP_DPP_MIN(0x114, 0xf) DMPP_DPP_MIN(0x118, 0xf)
+    DMPP_DPP_MIN(0x142, 0xa) DMPP_DPP_MIN(0x143, 0xc)
+#undef DMPP_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ int popc_m(uint32_t v) { return __popc(v); }
+__device__ __forceinline__ int popc_m(uint64_t v) { return __popcll(v); }
+__device__ __forceinline__ int lsb_m(uint32_t v) { return __ffs((int)v) - 1; }
+__device__ __forceinline__ int lsb_m(uint64_t v) { return __ffsll((long long)v) - 1; }
+__device__ __forceinline__ int msb_m(uint32_t v) { return 31 - __clz((int)v); }
+__device__ __forceinline__ int msb_m(uint64_t v) { return 63 - __clzll((long long)v); }
+
+// ---------------------------------------------------------------------------------------
+// Views.  A "view" is a bit matrix of NL lines x LW words of 32 cells: the row-major one for E/W travel (line = y,
+// position along the line = x) or the column-major one for N/S (line = x, position = y); the forced-neighbour test only
+// needs the two neighbouring lines, so both axes share the code.  A line is described by LineM: `mask` has bit w set when
+// word w of the line may hold an obstacle bit (a scan only ever visits such words), `off` locates the line's words.
+constexpr uint32_t kLineOutside = 0xFFFFFFFFu;          // LineM.off of a line outside the grid: every cell blocked
+template <class M> struct LineM { M mask; uint32_t off; };
+
+// Sparse view in LDS: only the words flagged in `mask` are stored, in word order, from data[off].
+//   K = 0: LW <= 16, one u32 per line (mask | off << 16);  K = 1: LW <= 32, uint2 {mask, off};
+//   K = 2: LW <= 64, u64 mask[] and u32 off[].
+template <int K>
+struct SparseView {
+    using M = std::conditional_t<K == 2, uint64_t, uint32_t>;
+    uint32_t* data; void* meta; uint32_t* off2; int LW, NL;
+
+    __device__ __forceinline__ LineM<M> line(int l) const
+    {
+        LineM<M> r; r.mask = 0; r.off = kLineOutside;
+        if ((unsigned)l < (unsigned)NL) {
+            if constexpr (K == 0) { const uint32_t v = reinterpret_cast<const uint32_t*>(meta)[l]; r.mask = v & 0xFFFFu; r.off = v >> 16; }
+            else if constexpr (K == 1) { const uint2 v = reinterpret_cast<const uint2*>(meta)[l]; r.mask = v.x; r.off = v.y; }
+            else { r.mask = reinterpret_cast<const uint64_t*>(meta)[l]; r.off = off2[l]; }
+        }
+        return r;
+    }
+    __device__ __forceinline__ uint32_t word(const LineM<M>& m, int w) const
+    {
+        if (m.off == kLineOutside || (unsigned)w >= (unsigned)LW) return 0xFFFFFFFFu;
+        const M bit = (M)1 << w;
+        if (!(m.mask & bit)) return 0u;
+        return data[m.off + popc_m((M)(m.mask & (bit - 1)))];
+    }
+    // ---- construction (setup waves) ----
+    __device__ __forceinline__ void clear_line(int l) const
+    {
+        if constexpr (K == 0) reinterpret_cast<uint32_t*>(meta)[l] = 0;
+        else if constexpr (K == 1) reinterpret_cast<uint2*>(meta)[l] = make_uint2(0u, 0u);
+        else { reinterpret_cast<uint64_t*>(meta)[l] = 0; off2[l] = 0; }
+    }
+    __device__ __forceinline__ void or_mask(int l, M bits) const
+    {
+        if constexpr (K == 0) atomicOr(&reinterpret_cast<uint32_t*>(meta)[l], (uint32_t)bits);
+        else if constexpr (K == 1) atomicOr(&reinterpret_cast<uint2*>(meta)[l].x, (uint32_t)bits);
+        else atomicOr(reinterpret_cast<unsigned long long*>(&reinterpret_cast<uint64_t*>(meta)[l]), (unsigned long long)bits);
+    }
+    __device__ __forceinline__ M mask_of(int l) const
+    {
+        if constexpr (K == 0) return reinterpret_cast<const uint32_t*>(meta)[l] & 0xFFFFu;
+        else if constexpr (K == 1) return reinterpret_cast<const uint2*>(meta)[l].x;
+        else return reinterpret_cast<const uint64_t*>(meta)[l];
+    }
+    __device__ __forceinline__ void set_off(int l, uint32_t off) const
+    {
+        if constexpr (K == 0) reinterpret_cast<uint32_t*>(meta)[l] |= off << 16;
+        else if constexpr (K == 1) reinterpret_cast<uint2*>(meta)[l].y = off;
+        else off2[l] = off;
+    }
+};
+template <int K> __host__ __device__ constexpr int sparse_meta_bytes_per_line() { return K == 0 ? 4 : (K == 1 ? 8 : 12); }
+
+// Dense view: the bitmap of k_rasterise in HBM, one u64 mask per line in LDS (bit w = word w is non-zero).
+struct DenseView {
+    using M = uint64_t;
+    const uint32_t* base; const uint64_t* nz; int LW, NL;
+    __device__ __forceinline__ LineM<M> line(int l) const
+    {
+        LineM<M> r; r.mask = 0; r.off = kLineOutside;
+        if ((unsigned)l < (unsigned)NL) { r.mask = nz[l]; r.off = (uint32_t)(l * LW); }
+        return r;
+    }
+    __device__ __forceinline__ uint32_t word(const LineM<M>& m, int w) const
+    {
+        if (m.off == kLineOutside || (unsigned)w >= (unsigned)LW) return 0xFFFFFFFFu;
+        if (!((m.mask >> w) & 1ull)) return 0u;
+        return base[m.off + w];
+    }
+};
+
+// single-cell test on the row-major view: outside the grid = blocked
+template <class V>
+__device__ __forceinline__ bool cell_blocked(const V& rowv, int x, int y)
+{
+    if ((unsigned)x >= (unsigned)(rowv.LW << 5)) return true;
+    const auto m = rowv.line(y);
+    return (rowv.word(m, x >> 5) >> (x & 31)) & 1u;
+}
+template <class V, class L>
+__device__ __forceinline__ bool cell_blocked_m(const V& v, const L& m, int p)       // cell at position p of a line already described by m
+{
+    if ((unsigned)p >= (unsigned)(v.LW << 5)) return true;
+    return (v.word(m, p >> 5) >> (p & 31)) & 1u;
+}
+
+// run = cells travelled from `pos` along `line` in direction sgn to the first stop (blocked | forced | goal);
+// 0 = none (the first stop is a wall or the edge of the grid).  Safe for starts outside the grid (returns 0).
+// Only words whose mask bit is set in the line or one of its two neighbours (or that hold the goal) can contain a stop:
+// those candidate words are visited in travel order, nothing else is read.  m0 / mP / mM: the line and its neighbours
+// line + 1 / line - 1, loaded by the caller (the diagonal jump's cell tests share them).
+template <class V, class L>
+__device__ __forceinline__ int jump_lane(const V& vw, const L& m0, const L& mP, const L& mM, bool active, int line, int pos, int sgn,
+                                         int gline, int gpos, int* iters = nullptr)
+{
+    using M = typename V::M;
+    int run = 0;
+    bool go = active && (unsigned)line < (unsigned)vw.NL && (unsigned)pos < (unsigned)(vw.LW << 5);
+    const int w0 = pos >> 5;
+    M cand = 0;
+    if (go) {
+        cand = m0.mask | mP.mask | mM.mask;
+        if (gline == line) cand |= (M)1 << (gpos >> 5);
+        cand &= sgn > 0 ? (M)~((((M)1) << w0) - (M)1) : (M)((((M)2) << w0) - (M)1);     // the start word and everything ahead of it
+        go = cand != 0;
+    }
+    for (int it = 0; it <= vw.LW; it++) {
+        if (!__ballot(go)) break;
+        if (iters) ++*iters;
+        if (go) {
+            const int wi = sgn > 0 ? lsb_m(cand) : msb_m(cand);
+            cand &= (M)~(((M)1) << wi);
+            const uint32_t B0 = vw.word(m0, wi);
+            const uint32_t P = vw.word(mP, wi), Mi = vw.word(mM, wi);
+            // the neighbour's next word along the travel only matters for the last cell of this word, and only when the
+            // neighbour is blocked there
+            uint32_t Pn, Mn;
+            if (sgn > 0) {
+                const uint32_t Pw = (P >> 31) ? vw.word(mP, wi + 1) : 0u, Mw = (Mi >> 31) ? vw.word(mM, wi + 1) : 0u;
+                Pn = (P >> 1) | (Pw << 31); Mn = (Mi >> 1) | (Mw << 31);
+            } else {
+                const uint32_t Pw = (P & 1u) ? vw.word(mP, wi - 1) : 0u, Mw = (Mi & 1u) ? vw.word(mM, wi - 1) : 0u;
+                Pn = (P << 1) | (Pw >> 31); Mn = (Mi << 1) | (Mw >> 31);
+            }
+            uint32_t stop = B0 | (P & ~Pn) | (Mi & ~Mn);
+            if (gline == line && (gpos >> 5) == wi) stop |= 1u << (gpos & 31);
+            if (wi == w0) {                                  // only the cells strictly ahead of the start
+                const int bp = pos & 31;
+                if (sgn > 0) stop &= (bp == 31) ? 0u : ~((2u << bp) - 1u);
+                else         stop &= (1u << bp) - 1u;
+            }
+            if (stop) {
+                const int bit = sgn > 0 ? (__ffs((int)stop) - 1) : (31 - __clz((int)stop));
+                if (!((B0 >> bit) & 1u)) { const int np = (wi << 5) + bit; run = sgn > 0 ? np - pos : pos - np; }
+                go = false;
+            } else if (cand == 0) go = false;                // free all the way to the edge of the grid: no jump point
+        }
+    }
+    return run;
+}
+
+// ---------------------------------------------------------------------------------------
+// G1 inside the search: the footprint of one obstacle, exactly as oracle/dmpp_grid_oracle.c defines it - cell (ix, iy)
+// is occupied iff  dx*dx + dy*dy <= R*R  for its centre, R = radius + inflate - but produced span by span.
+// For a fixed row the predicate is true on a contiguous run of columns (every step of its evaluation is monotone in the
+// distance of the column from the obstacle, rounding included), so a row is described by its first and last true column;
+// both are found from a sqrt estimate and then MOVED BY THE PREDICATE ITSELF until exact.  Columns likewise.
+struct Footprint { double ox, oy, R2; int ix0, ix1, iy0, iy1; };
+
+__device__ __forceinline__ Footprint footprint_of(const PlannerConfig& c, GlobalPoint2D origin, const ObPoint& o, int W, int H)
+{
+    Footprint f;
+    const double R = (double)o.radius + c.inflate;
+    f.ox = o.x; f.oy = o.y; f.R2 = R * R;
+    // the conservative box of the oracle's rasteriser, clipped to the grid
+    f.ix0 = max((int)floor((o.x - R - origin.x) / c.cell) - 1, 0);
+    f.ix1 = min((int)floor((o.x + R - origin.x) / c.cell) + 1, W - 1);
+    f.iy0 = max((int)floor((o.y - R - origin.y) / c.cell) - 1, 0);
+    f.iy1 = min((int)floor((o.y + R - origin.y) / c.cell) + 1, H - 1);
+    return f;
+}
+
+// Exact run [a, b] of indices i in [lo, hi] with  du(i)^2 + dv2 <= R2,  du(i) = (org + (i + 0.5) * cell) - ou.
+// `ic` = floor((ou - org) / cell), the index whose centre is nearest to ou (or next to it).  Returns false when empty.
+__device__ __forceinline__ bool exact_span(double ou, double org, double cell, double inv_cell, double dv2, double R2, int ic,
+                                           int lo, int hi, int& a, int& b)
+{
+    auto pred = [&](int i) { const double du = (org + ((double)i + 0.5) * cell) - ou; return du * du + dv2 <= R2; };
+    int t;
+    if (pred(ic)) t = ic; else if (pred(ic - 1)) t = ic - 1; else if (pred(ic + 1)) t = ic + 1; else return false;
+    if (t < lo) { if (!pred(lo)) return false; }         // the run contains t: it reaches the window only through lo
+    if (t > hi) { if (!pred(hi)) return false; }
+    const double half = sqrt(fmax(R2 - dv2, 0.0));
+    a = clampi((int)ceil((ou - half - org) * inv_cell - 0.5), lo, max(min(t, hi), lo));
+    b = clampi((int)floor((ou + half - org) * inv_cell - 0.5), min(max(t, lo), hi), hi);
+    while (a > lo && pred(a - 1)) a--;
+    while (a <= hi && !pred(a)) a++;
+    if (a > hi) return false;
+    while (b < hi && pred(b + 1)) b++;
+    while (b >= a && !pred(b)) b--;
+    return b >= a;
+}
+
+// bits [p0, p1] of a line as (word, mask) pieces
+template <class F>
+__device__ __forceinline__ void for_words(int p0, int p1, F&& f)
+{
+    for (int w = p0 >> 5; w <= (p1 >> 5); w++) {
+        const int lo = max(p0 - (w << 5), 0), hi = min(p1 - (w << 5), 31);
+        const uint32_t bits = (hi == 31 ? 0xFFFFFFFFu : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
+        f(w, bits);
+    }
+}
+
+// exclusive prefix sum over the 256 threads of the setup block (wave scan by shuffles, waves joined through LDS)
+__device__ __forceinline__ int block_excl_scan(int v, int tid, int* s_wave /* [kSearchSetupWaves + 1] */)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int sft = 1; sft < DMPP_WAVE; sft <<= 1) { const int t = __shfl_up(incl, sft, 64); if (lane >= sft) incl += t; }
+    if (lane == DMPP_WAVE - 1) s_wave[wv] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int q = 0; q < kSearchSetupWaves; q++) { const int t = s_wave[q]; if (q < wv) base += t; total += t; }
+    if (tid == 0) s_wave[kSearchSetupWaves] = total;
+    __syncthreads();
+    return base + incl - v;
+}
+
+// Builds both sparse views of a scene from its obstacle list.  All kSearchBlock threads; returns the words the larger view
+// needs (> budget: nothing was filled, the views are unusable).  The masks come from the obstacles' bounding boxes (a
+// superset: a few stored words stay zero), the bits from the exact spans.
+template <int K>
+__device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m,
+                                         const SparseView<K>& vr, const SparseView<K>& vc, int budget, int* s_wave)
+{
+    using M = typename SparseView<K>::M;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int W = c.grid_w, H = c.grid_h;
+    const bool colhalf = lane >= 32;                        // lanes 0..31: rows of the footprint, 32..63: its columns
+    const int l32 = lane & 31;
+    for (int l = tid; l < H; l += kSearchBlock) vr.clear_line(l);
+    for (int l = tid; l < W; l += kSearchBlock) vc.clear_line(l);
+    __syncthreads();
+    // ---- pass 1: which words of which lines a footprint's box touches ----
+    for (int j = wv; j < m; j += kSearchSetupWaves) {
+        const Footprint f = footprint_of(c, si.grid_origin, obs[j], W, H);
+        if (f.ix1 < f.ix0 || f.iy1 < f.iy0) continue;
+        const int l0 = colhalf ? f.ix0 : f.iy0, l1 = colhalf ? f.ix1 : f.iy1;
+        const int p0 = colhalf ? f.iy0 : f.ix0, p1 = colhalf ? f.iy1 : f.ix1;
+        const int wa = p0 >> 5, wb = p1 >> 5;
+        const M bits = (M)((wb - wa >= (int)(8 * sizeof(M)) - 1) ? ~(M)0 : ((((M)2) << (wb - wa)) - (M)1)) << wa;
+        for (int l = l0 + l32; l <= l1; l += 32) { if (colhalf) vc.or_mask(l, bits); else vr.or_mask(l, bits); }
+    }
+    __syncthreads();
+    // ---- offsets: exclusive prefix sum of the word counts over the lines, per view ----
+    auto place = [&](const SparseView<K>& vw) {
+        const int NL = vw.NL, per = (NL + kSearchBlock - 1) / kSearchBlock;
+        const int l0 = tid * per, l1 = min(l0 + per, NL);
+        int cnt = 0;
+        for (int l = l0; l < l1; l++) cnt += popc_m(vw.mask_of(l));
+        int off = block_excl_scan(cnt, tid, s_wave);
+        const int total = s_wave[kSearchSetupWaves];
+        for (int l = l0; l < l1; l++) { const int k = popc_m(vw.mask_of(l)); vw.set_off(l, (uint32_t)off); off += k; }
+        __syncthreads();
+        return total;
+    };
+    const int total_r = place(vr), total_c = place(vc);
+    const int need = max(total_r, total_c);
+    if (need > budget) return need;
+    for (int i = tid; i < total_r; i += kSearchBlock) vr.data[i] = 0;
+    for (int i = tid; i < total_c; i += kSearchBlock) vc.data[i] = 0;
+    __syncthreads();
+    // ---- pass 2: the exact spans ----
+    const double inv_cell = 1.0 / c.cell;
+    for (int j = wv; j < m; j += kSearchSetupWaves) {
+        const Footprint f = footprint_of(c, si.grid_origin, obs[j], W, H);
+        if (f.ix1 < f.ix0 || f.iy1 < f.iy0) continue;
+        const double ou = colhalf ? f.oy : f.ox, ov = colhalf ? f.ox : f.oy;                 // along the line / across the lines
+        const double org_u = colhalf ? si.grid_origin.y : si.grid_origin.x, org_v = colhalf ? si.grid_origin.x : si.grid_origin.y;
+        const int ic = (int)floor((ou - org_u) / c.cell);
+        const int l0 = colhalf ? f.ix0 : f.iy0, l1 = colhalf ? f.ix1 : f.iy1;
+        const int lo = colhalf ? f.iy0 : f.ix0, hi = colhalf ? f.iy1 : f.ix1;
+        const SparseView<K> vw = colhalf ? vc : vr;         // by value: per-lane field selects, no stack object
+        for (int l = l0 + l32; l <= l1; l += 32) {
+            const double dv = (org_v + ((double)l + 0.5) * c.cell) - ov;
+            int a, b;
+            if (!exact_span(ou, org_u, c.cell, inv_cell, dv * dv, f.R2, ic, lo, hi, a, b)) continue;
+            const LineM<M> lm = vw.line(l);
+            for_words(a, b, [&](int w, uint32_t bits) {
+                atomicOr(&vw.data[lm.off + popc_m((M)(lm.mask & ((((M)1) << w) - (M)1)))], bits);
+            });
+        }
+    }
+    __syncthreads();
+    return need;
+}
+
+// clears one cell in a sparse view (the start cell is always free)
+template <int K>
+__device__ __forceinline__ void sparse_clear_cell(const SparseView<K>& vw, int line, int pos)
+{
+    using M = typename SparseView<K>::M;
+    const LineM<M> lm = vw.line(line);
+    const int w = pos >> 5;
+    if (lm.mask & (((M)1) << w)) vw.data[lm.off + popc_m((M)(lm.mask & ((((M)1) << w) - (M)1)))] &= ~(1u << (pos & 31));
+}
+
+// ---------------------------------------------------------------------------------------
+struct SearchLds {                               // the static LDS of a searching workgroup (10.3 KB)
+    uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24
+    uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
+    uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
+    uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
+    uint16_t c_info[kClosedTab];    // arriving direction | run length << 4 of the cell in the same slot
+    int dc_owner[kMaxDiag];         // the (node, s) lanes of the diagonal jumps of the current step
+    uint32_t sj_job[kDiagGroup];    // its straight jumps (<= 8), packed
+    int s_wave[kSearchSetupWaves + 1];
+    int s_flag;
+};
+
+struct SearchOut { int status, n_exp, n_push, n_rounds, path_cost, path_len; uint64_t digest; };
+
+// The search proper, one wave.  Vrow / Vcol: the two views; closed / pin: this scene's spill area in HBM.
+template <class V>
+__device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchLds& L, const V& Vrow, const V& Vcol, int start, int goal, int order_cap,
+                                        uint32_t* __restrict__ closed, uint16_t* __restrict__ pin, int32_t* __restrict__ order,
+                                        int32_t* __restrict__ path, int lane
+#ifdef DMPP_DEBUG_SEARCH
+                                        , long long* dbg_t, int* dbg_c
+#endif
+                                        )
+{
+#ifdef DMPP_DEBUG_SEARCH
+#define DBG_MARK(slot) { const long long t__ = clock64(); dbg_t[slot] += t__ - dbg_last; dbg_last = t__; }
+    long long dbg_last = clock64();
+#else
+#define DBG_MARK(slot)
+#endif
+    const int W = c.grid_w, H = c.grid_h, N = W * H;
+    const int gx = goal % W, gy = goal / W;
+    const int cap = min(c.bucket_cap, kOpenCap);
+    SearchOut R; R.status = -1; R.n_exp = 0; R.n_push = 1; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
+    int status = -1, n_exp = 0, n_push = 1, n_rounds = 0, path_cost = 0;
+    uint64_t digest = 0;
+    bool hash_complete = true;                 // every closed cell is in the LDS hash (with its direction and run)
+    int n_open = 1, live = 1, fmax = -1;
+    // lane = node * 8 + s: the eight directions of each of the (<= 4) nodes of a step
+    const int s = lane & 7;
+    const int sdx = (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0);
+    const int sdy = (s >= 1 && s <= 3) ? 1 : ((s >= 5) ? -1 : 0);
+    long long guard = 16ll * N + 1024;                 // every iteration pops an entry; entries <= 8 per closed cell
+    while (status < 0) {
+        if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
+#ifdef DMPP_DEBUG_SEARCH
+        dbg_c[0]++;
+#endif
+        if (live == 0) { status = DMPP_G_NO_PATH; break; }
+        // ---- pop: up to 4 entries of the smallest f, the latest pushes first ----
+        // (1) squeeze the dead slots out when they outnumber the live ones: the scans below stay short
+        if ((n_open - live > 64 && n_open > 2 * live)) {
+            int w = 0;
+            for (int q0 = 0; q0 < n_open; q0 += DMPP_WAVE) {
+                const int i = q0 + lane;
+                uint32_t f2 = 0xFFFFu, ee = 0; uint16_t rr = 0;
+                if (i < n_open) { f2 = L.o_f2[i]; ee = L.o_ent[i]; rr = L.o_run[i]; }
+                const bool alive = f2 != 0xFFFFu;
+                const unsigned long long am = __ballot(alive);
+                wave_order();
+                if (alive) {
+                    const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+                    L.o_f2[w + r] = (uint16_t)f2; L.o_ent[w + r] = ee; L.o_run[w + r] = rr;
+                }
+                w += __popcll(am);
+                wave_order();
+            }
+            n_open = w;
+        }
+        // (2) the first 256 slots are cached in registers: one LDS pass serves both the minimum and the ties
+        uint32_t v0 = 0xFFFFu, v1 = 0xFFFFu, v2 = 0xFFFFu, v3 = 0xFFFFu;
+        if (lane < n_open) v0 = L.o_f2[lane];
+        if (lane + 64 < n_open) v1 = L.o_f2[lane + 64];
+        if (lane + 128 < n_open) v2 = L.o_f2[lane + 128];
+        if (lane + 192 < n_open) v3 = L.o_f2[lane + 192];
+        uint32_t key = min(min(v0, v1), min(v2, v3));
+        for (int i = lane + 256; i < n_open; i += DMPP_WAVE) { const uint32_t f2 = L.o_f2[i]; if (f2 < key) key = f2; }
+        const uint32_t fmin2 = wave_min_u32(key);
+        if (fmin2 == 0xFFFFu) { status = DMPP_G_INTERNAL; break; }
+        const int f = (int)fmin2 << 1;
+        int nt = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+        for (int c0 = ((n_open - 1) >> 6) << 6; c0 >= 0 && nt < DMPP_JPS_BATCH; c0 -= DMPP_WAVE) {
+            const int i = c0 + lane;
+            bool tie;
+            if (c0 == 0) tie = v0 == fmin2; else if (c0 == 64) tie = v1 == fmin2; else if (c0 == 128) tie = v2 == fmin2;
+            else if (c0 == 192) tie = v3 == fmin2; else tie = i < n_open && L.o_f2[i] == fmin2;
+            unsigned long long tm = __ballot(tie);
+            while (tm && nt < DMPP_JPS_BATCH) {
+                const int Lm = 63 - __clzll((long long)tm);
+                tm &= ~(1ull << Lm);
+                const int idx = c0 + Lm;
+                if (nt == 0) i0 = idx; else if (nt == 1) i1 = idx; else if (nt == 2) i2 = idx; else i3 = idx;
+                nt++;
+            }
+        }
+        const int myi = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : i3;
+        const bool have = lane < nt;
+        uint32_t e = 0; int run_in = 0;
+        if (have) { e = L.o_ent[myi]; run_in = L.o_run[myi]; }
+        wave_order();
+        if (have) L.o_f2[myi] = 0xFFFFu;
+        live -= nt;
+        if (i0 == n_open - 1) n_open--;
+        const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu), d = (int)(e >> 24);
+        const int cell = y * W + x;
+        DBG_MARK(0)
+#ifdef DMPP_DEBUG_SEARCH
+        dbg_c[1] += nt;
+#endif
+        // ---- closed?  duplicates inside the batch: the earlier one wins; then the closed set ----
+        bool valid = have;
+        {
+            const int c0_ = __builtin_amdgcn_readlane(cell, 0), c1_ = __builtin_amdgcn_readlane(cell, 1), c2_ = __builtin_amdgcn_readlane(cell, 2);
+            if ((lane == 1 && cell == c0_) || (lane == 2 && (cell == c0_ || cell == c1_)) ||
+                (lane == 3 && (cell == c0_ || cell == c1_ || cell == c2_))) valid = false;
+        }
+        if (n_exp + DMPP_JPS_BATCH <= kClosedMax) {
+            if (valid) {
+                const uint32_t keyc = (uint32_t)cell + 1u;
+                uint32_t hh = ((uint32_t)cell * 2654435761u) >> (32 - kClosedLog);
+                for (int probe = 0; probe < kClosedTab; probe++) {
+                    const uint32_t old = atomicCAS(&L.c_tab[hh], 0u, keyc);
+                    if (old == 0u) { L.c_info[hh] = (uint16_t)(d | (run_in << 4)); break; }   // inserted: was open
+                    if (old == keyc) { valid = false; break; }            // already closed
+                    hh = (hh + 1) & (kClosedTab - 1);
+                }
+            }
+        } else {
+            if (hash_complete) {
+                // ---- spill: this scene outgrows the LDS hash.  Its bit set in HBM is zeroed now, not at launch (most scenes
+                //      never get here), the hash is replayed into it, and from here on the bit set answers. ----
+                hash_complete = false;
+                uint4* c4 = reinterpret_cast<uint4*>(closed);
+                const uint4 z = { 0u, 0u, 0u, 0u };
+                for (int i = lane; i < (N >> 7); i += DMPP_WAVE) c4[i] = z;
+                __threadfence();
+                wave_sync();
+                for (int i = lane; i < kClosedTab; i += DMPP_WAVE) {
+                    const uint32_t e2 = L.c_tab[i];
+                    if (e2) { const int cc = (int)e2 - 1; atomicOr(&closed[cc >> 5], 1u << (cc & 31)); pin[cc] = L.c_info[i]; }
+                }
+                __threadfence();
+                wave_sync();
+            }
+            if (valid) {
+                const uint32_t old = atomicOr(&closed[cell >> 5], 1u << (cell & 31));
+                if ((old >> (cell & 31)) & 1u) valid = false;
+            }
+        }
+        // the goal, or the entry that reaches the expansion limit, ends the search at once
+        unsigned vm = (unsigned)__ballot(valid) & 0xFu;
+        {
+            const int nvb = __popc(vm & ((1u << lane) - 1u));
+            const unsigned stop = (unsigned)__ballot(valid && (cell == goal || n_exp + nvb + 1 >= c.max_expansions)) & 0xFu;
+            if (stop) {
+                const int last = __ffs((int)stop) - 1;
+                if (lane > last) valid = false;
+                vm = (unsigned)__ballot(valid) & 0xFu;
+            }
+        }
+        if (valid) {
+            const int seq = n_exp + __popc(vm & ((1u << lane) - 1u));
+            if (!hash_complete) pin[cell] = (uint16_t)(d | (run_in << 4));
+            if (order && seq < order_cap) order[seq] = cell;
+            digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell);
+        }
+        if (vm && f > fmax) { fmax = f; n_rounds++; }
+        n_exp += __popc(vm);
+        if (__ballot(valid && cell == goal)) { status = DMPP_G_FOUND; path_cost = f; break; }
+        if (n_exp >= c.max_expansions) { status = DMPP_G_LIMIT; break; }
+        if (vm == 0) continue;
+        DBG_MARK(1)
+        // ---- successors: lane = node * 8 + s for the (<= 4) batch nodes ----
+        const int node = lane >> 3;
+        const int nx0 = __shfl(x, node, 64), ny0 = __shfl(y, node, 64), nd = __shfl(d, node, 64);
+        const bool nvalid = lane < 32 && ((vm >> node) & 1u);
+        const int gcur = f - hfun(nx0, ny0, gx, gy);
+        bool want_jump = false, want_diag = false; int run = 0;
+        {
+            const int dd = nd & 7;
+            const int ddx = (dd == 0 || dd == 1 || dd == 7) ? 1 : ((dd >= 3 && dd <= 5) ? -1 : 0);
+            const int ddy = (dd >= 1 && dd <= 3) ? 1 : ((dd >= 5) ? -1 : 0);
+            const int rel = (s - nd) & 7;
+            const bool is_start = nd == 8, d_odd = (nd & 1) != 0 && !is_start, d_even = !d_odd && !is_start;
+            want_jump = nvalid && ((is_start && (s & 1) == 0) || (d_even && rel == 0) || (d_odd && (rel == 1 || rel == 7)));
+            const bool plain = nvalid && ((is_start && (s & 1) != 0) || (d_odd && rel == 0));
+            const bool sided = nvalid && ((d_even && (rel == 1 || rel == 7)) || (d_odd && (rel == 2 || rel == 6)));
+            const int px = d_odd ? (sdx - ddx) / 2 : sdx - ddx, py = d_odd ? (sdy - ddy) / 2 : sdy - ddy;
+            const bool t_free = (plain || sided) && !cell_blocked(Vrow, nx0 + sdx, ny0 + sdy);
+            const bool side_blk = sided && cell_blocked(Vrow, nx0 + px, ny0 + py);
+            want_diag = (plain && t_free) || (sided && side_blk && t_free);
+        }
+        DBG_MARK(2)
+        // ---- jumps.  Every straight scan is one lane (jump_lane).  A diagonal jump takes a group of kDiagGroup = 16
+        //      lanes: lane pair k = 0..6 scans horizontally | vertically from cell k+1 of the diagonal and its even lane
+        //      tests that cell (blocked / goal / forced); cell 8 only needs the test (whatever a scan found there, the
+        //      jump ends at that cell), so the last pair of every group is free for the straight successors of the
+        //      batch (<= 8; 4 for the start node).  Four diagonal jumps + all straight ones per round; a second round
+        //      only when a step has more than four diagonal successors.  The first cell with a finding ends a jump. ----
+        const unsigned smask = (unsigned)__ballot(want_jump), dmask = (unsigned)__ballot(want_diag);
+        const int n_sj = __popc(smask), n_dc = __popc(dmask);
+        const int my_sj = __popc(smask & ((1u << (lane & 31)) - 1u)), my_dc = __popc(dmask & ((1u << (lane & 31)) - 1u));
+        if (want_jump) {
+            const bool horiz = s == 0 || s == 4;
+            // view | sgn | line | pos, 12 bits each for line and pos (always inside the grid here)
+            L.sj_job[my_sj] = (horiz ? 0u : 1u) | ((s == 0 || s == 2) ? 2u : 0u) | ((uint32_t)(horiz ? ny0 : nx0) << 2) | ((uint32_t)(horiz ? nx0 : ny0) << 14);
+        }
+        if (want_diag) L.dc_owner[my_dc] = lane;
+        wave_order();
+        const int n_rounds_j = (n_sj | n_dc) ? max(1, (n_dc + kDiagPerRound - 1) / kDiagPerRound) : 0;
+        for (int rnd = 0; rnd < n_rounds_j; rnd++) {
+            const int grp = lane / kDiagGroup, t = lane % kDiagGroup, kk = t >> 1;
+            const bool last = kk == kDiagK - 1;                                // the pair of cell 8 = the straight-jump lanes
+            const int dci = rnd * kDiagPerRound + grp;
+            const int sji = grp * 2 + (t & 1);
+            const bool dact = dci < n_dc, sact = rnd == 0 && last && sji < n_sj;
+            const int ol = L.dc_owner[dact ? dci : 0];
+            const int ox = __shfl(nx0, ol, 64), oy = __shfl(ny0, ol, 64);
+            const int os = ol & 7;
+            const int odx = (os == 1 || os == 7) ? 1 : -1, ody = (os == 1 || os == 3) ? 1 : -1;
+            const int cx = ox + (kk + 1) * odx, cy = oy + (kk + 1) * ody;
+            const uint32_t sj = L.sj_job[sact ? sji : 0];
+            bool hv = (t & 1) != 0;                                            // vertical scan?
+            int jl = hv ? cx : cy, jp = hv ? cy : cx, jsg = hv ? ody : odx;
+            if (last) { hv = (sj & 1u) != 0; jsg = (sj & 2u) ? 1 : -1; jl = (int)((sj >> 2) & 0xFFFu); jp = (int)(sj >> 14); }
+            const bool jact = last ? sact : dact;
+            const V vw = hv ? Vcol : Vrow;                                     // by value: per-lane field selects
+            // the scanned line and its two neighbours, described once: the scan and (horizontal lanes) the cell tests share them
+            const auto m0 = vw.line(jact || dact ? jl : -1), mP = vw.line(jact || dact ? jl + 1 : -1), mM = vw.line(jact || dact ? jl - 1 : -1);
+#ifdef DMPP_DEBUG_SEARCH
+            const int r = jump_lane(vw, m0, mP, mM, jact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx, &dbg_c[2]);
+#else
+            const int r = jump_lane(vw, m0, mP, mM, jact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx);
+#endif
+            bool cblk = false, cstop = false;
+            if (dact && (t & 1) == 0) {
+                // even lane of a pair: horizontal scan along row cy, so m0 / mP / mM are rows cy, cy + 1, cy - 1 of the row view
+                // (for the pair of cell 8 the lane scanned a straight job instead: its rows are looked up here)
+                const auto r0 = last ? Vrow.line(cy) : m0;
+                const auto ra = last ? Vrow.line(cy + ody) : (ody > 0 ? mP : mM);      // row cy + ody
+                const auto rb = last ? Vrow.line(cy - ody) : (ody > 0 ? mM : mP);      // row cy - ody
+                cblk = cell_blocked_m(Vrow, r0, cx);
+                const bool forced = (cell_blocked_m(Vrow, r0, cx - odx) && !cell_blocked_m(Vrow, ra, cx - odx)) ||
+                                    (cell_blocked_m(Vrow, rb, cx) && !cell_blocked_m(Vrow, rb, cx + odx));
+                cstop = cblk || (cx == gx && cy == gy) || forced;
+            }
+            const unsigned long long sm = __ballot(dact && (cstop || (!last && r > 0))), bk = __ballot(cblk);
+            const unsigned gs = (unsigned)(sm >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
+            const unsigned gb = (unsigned)(bk >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
+            int drun = kDiagK;
+            if (gs) { const int k1 = (__ffs((int)gs) - 1) >> 1; drun = ((gb >> (2 * k1)) & 1u) ? 0 : k1 + 1; }
+            // results back to the owner lanes: a straight one sits on lane 14 | 15 of group my_sj / 2, a diagonal one on its whole group
+            const int from_s = __shfl(r, ((my_sj >> 1) & (kDiagPerRound - 1)) * kDiagGroup + (kDiagGroup - 2) + (my_sj & 1), 64);
+            const int from_d = __shfl(drun, (my_dc & (kDiagPerRound - 1)) * kDiagGroup, 64);
+            if (rnd == 0 && want_jump) run = from_s;
+            if (want_diag && (my_dc / kDiagPerRound) == rnd) run = from_d;
+        }
+        DBG_MARK(3)
+#ifdef DMPP_DEBUG_SEARCH
+        dbg_c[3] += n_dc; dbg_c[4] += n_rounds_j;
+#endif
+        // ---- push in batch order, then direction order ----
+        const bool push = run > 0;
+        const unsigned pm = (unsigned)__ballot(push);
+        const int cnt = __popc(pm);
+        if (cnt) {
+            const int nx = nx0 + run * sdx, ny = ny0 + run * sdy;
+            const int fn = gcur + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
+            // f/2 lives in 16 bits (0xFFFF = dead slot): a push at or beyond DMPP_F_LIMIT ends the search.  The oracle tests
+            // each push in turn, the range before the capacity: the earlier of the two failing pushes decides the status.
+            const unsigned rm = (unsigned)__ballot(push && fn >= DMPP_F_LIMIT);
+            if (rm || live + cnt > cap) {
+                const int k_range = rm ? __popc(pm & ((1u << (__ffs((int)rm) - 1)) - 1u)) : 0x7FFFFFFF;
+                const int k_cap = live + cnt > cap ? cap - live : 0x7FFFFFFF;
+                status = k_range <= k_cap ? DMPP_G_COST_RANGE : DMPP_G_OVERFLOW;
+                break;
+            }
+            if (n_open + cnt > kOpenCap) {
+                // squeeze the dead slots out, keeping the push order (ballot + prefix popcount)
+                int w = 0;
+                for (int q0 = 0; q0 < n_open; q0 += DMPP_WAVE) {
+                    const int i = q0 + lane;
+                    uint32_t f2 = 0xFFFFu, ee = 0; uint16_t rr = 0;
+                    if (i < n_open) { f2 = L.o_f2[i]; ee = L.o_ent[i]; rr = L.o_run[i]; }
+                    const bool alive = f2 != 0xFFFFu;
+                    const unsigned long long am = __ballot(alive);
+                    wave_order();
+                    if (alive) {
+                        const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+                        L.o_f2[w + r] = (uint16_t)f2; L.o_ent[w + r] = ee; L.o_run[w + r] = rr;
+                    }
+                    w += __popcll(am);
+                    wave_order();
+                }
+                n_open = w;
+            }
+            if (push) {
+                const int slot = n_open + __popc(pm & ((1u << lane) - 1u));
+                L.o_f2[slot] = (uint16_t)(fn >> 1);
+                L.o_ent[slot] = (uint32_t)nx | ((uint32_t)ny << 12) | ((uint32_t)s << 24);
+                L.o_run[slot] = (uint16_t)run;
+            }
+            n_open += cnt; live += cnt; n_push += cnt;
+            wave_order();
+        }
+        DBG_MARK(4)
+    }
+    DBG_MARK(5)
+
+    // ---- reduce the digest, rebuild the path from the runs ----
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        uint32_t lo = (uint32_t)digest, hi = (uint32_t)(digest >> 32);
+        lo = __shfl_xor((int)lo, sft, 64); hi = __shfl_xor((int)hi, sft, 64);
+        digest += ((uint64_t)hi << 32) | lo;
+    }
+    int path_len = 0;
+    bool slow_walk = !hash_complete;           // the HBM copy of direction | run answers instead of the LDS hash
+    if (status == DMPP_G_FOUND && hash_complete) {
+        // Walk the runs back from the goal: lane 0 looks each closed cell up in the LDS hash (direction and run sit in
+        // the same slot) and lists the hops in the LDS arrays of the dead open list.  The length is then known before
+        // a cell is written, so every cell goes straight to its final place, path[keep-1-k] for the k-th cell counted
+        // from the goal: one lane per hop, offsets from a wave prefix sum of the run lengths.
+        int Lc = 1, hops = 0, bad = 0;         // bad: 1 = inconsistent closed set, 2 = more hops than the LDS list holds
+        if (lane == 0) {
+            int cur = goal;
+            while (cur != start) {
+                if (hops >= kOpenCap) { bad = 2; break; }
+                uint32_t hh = ((uint32_t)cur * 2654435761u) >> (32 - kClosedLog);
+                int v = -1;
+                for (int probe = 0; probe < kClosedTab; probe++) {
+                    const uint32_t e2 = L.c_tab[hh]; const int inf = L.c_info[hh];
+                    if (e2 == (uint32_t)cur + 1u) { v = inf; break; }
+                    if (e2 == 0u) break;
+                    hh = (hh + 1) & (kClosedTab - 1);
+                }
+                const int pd = v & 15, rn = v >> 4;
+                if (v < 0 || rn == 0 || pd > 7) { bad = 1; break; }
+                // dx, dy of direction pd from two packed tables (2 bits each, value + 1)
+                const int dx = (int)((0x901Au >> (2 * pd)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * pd)) & 3u) - 1;
+                const int step = dy * W + dx;
+                L.o_ent[hops] = (uint32_t)cur; L.o_run[hops] = (uint16_t)rn; L.o_f2[hops] = (uint16_t)pd;
+                hops++; Lc += rn; cur -= rn * step;
+            }
+        }
+        Lc = __builtin_amdgcn_readfirstlane(Lc);
+        hops = __builtin_amdgcn_readfirstlane(hops);
+        bad = __builtin_amdgcn_readfirstlane(bad);
+        wave_sync();
+        if (bad == 1) status = DMPP_G_INTERNAL;
+        else if (bad == 2) {
+            // more hops than the LDS list holds: spill the hash to HBM and take the chunked walk below
+            uint4* c4 = reinterpret_cast<uint4*>(closed);
+            (void)c4;
+            for (int i = lane; i < kClosedTab; i += DMPP_WAVE) {
+                const uint32_t e2 = L.c_tab[i];
+                if (e2) pin[(int)e2 - 1] = L.c_info[i];
+            }
+            __threadfence();
+            wave_sync();
+            slow_walk = true;
+        } else {
+            int keep = Lc;
+            if (Lc > c.max_path) { keep = c.max_path; status = DMPP_G_PATH_TRUNC; }
+            path_len = keep;
+            int kbase = 0;
+            for (int j0 = 0; j0 < hops; j0 += DMPP_WAVE) {
+                const int j = j0 + lane;
+                const int rn = j < hops ? (int)L.o_run[j] : 0;
+                int incl = rn;
+#pragma unroll
+                for (int sft = 1; sft < DMPP_WAVE; sft <<= 1) { const int t = __shfl_up(incl, sft, 64); if (lane >= sft) incl += t; }
+                int ec = 0, step = 0;
+                const int idx0 = kbase + incl - rn;
+                if (rn) {
+                    const int pd = L.o_f2[j];
+                    ec = (int)L.o_ent[j];
+                    const int dx = (int)((0x901Au >> (2 * pd)) & 3u) - 1, dy = (int)((0x01A9u >> (2 * pd)) & 3u) - 1;
+                    step = dy * W + dx;
+                }
+                // short runs (diagonal jumps, hops between close jump points): the hop's lane writes its cells; long
+                // straight runs: the whole wave writes one run together
+                constexpr int kLongRun = 12;
+                if (rn && rn <= kLongRun) { int idx = idx0; for (int r = 0; r < rn && idx < keep; r++, idx++) path[keep - 1 - idx] = ec - r * step; }
+                unsigned long long lm = __ballot(rn > kLongRun);
+                while (lm) {
+                    const int src = __ffsll((long long)lm) - 1;
+                    lm &= lm - 1;
+                    const int h_ec = __shfl(ec, src, 64), h_step = __shfl(step, src, 64), h_rn = __shfl(rn, src, 64), h_idx = __shfl(idx0, src, 64);
+                    for (int r = lane; r < h_rn; r += DMPP_WAVE) if (h_idx + r < keep) path[keep - 1 - (h_idx + r)] = h_ec - r * h_step;
+                }
+                kbase += __shfl(incl, DMPP_WAVE - 1, 64);
+            }
+            if (lane == 0 && keep == Lc) path[0] = start;
+        }
+    }
+    if (status == DMPP_G_FOUND && slow_walk) {
+        // Walk the runs back from the goal (lane 0 follows dir/run of each closed cell; it wrote them
+        // itself), a chunk of runs at a time through the LDS arrays of the dead open list; all lanes
+        // write the cells of a chunk goal-first into path[], which is reversed in place at the end.
+        int cur = goal, k = 0;                            // k = cells written so far (goal side)
+        bool done = false, broken = false;
+        while (!done && !broken) {
+            int hops = 0;
+            if (lane == 0) {
+                int kk = k;
+                while (cur != start && hops < kOpenCap) {
+                    const int v = pin[cur];
+                    const int pd = v & 15, rn = v >> 4;
+                    if (rn == 0 || pd > 7 || kk > N) { broken = true; break; }
+                    const int dx = (pd == 0 || pd == 1 || pd == 7) ? 1 : ((pd >= 3 && pd <= 5) ? -1 : 0);
+                    const int dy = (pd >= 1 && pd <= 3) ? 1 : ((pd >= 5) ? -1 : 0);
+                    L.o_ent[hops] = (uint32_t)cur; L.o_run[hops] = (uint16_t)rn; L.o_f2[hops] = (uint16_t)pd;
+                    hops++; kk += rn;
+                    cur -= rn * (dy * W + dx);
+                }
+                done = cur == start;
+            }
+            hops = __builtin_amdgcn_readfirstlane(hops);
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            done = __builtin_amdgcn_readfirstlane((int)done) != 0;
+            broken = __builtin_amdgcn_readfirstlane((int)broken) != 0;
+            wave_sync();
+            for (int j = 0; j < hops; j++) {
+                const int ec = (int)L.o_ent[j], rn = L.o_run[j], pd = L.o_f2[j];
+                const int dx = (pd == 0 || pd == 1 || pd == 7) ? 1 : ((pd >= 3 && pd <= 5) ? -1 : 0);
+                const int dy = (pd >= 1 && pd <= 3) ? 1 : ((pd >= 5) ? -1 : 0);
+                const int step = dy * W + dx;
+                for (int r = lane; r < rn; r += DMPP_WAVE)
+                    if (k + r < c.max_path) path[k + r] = ec - r * step;
+                k += rn;
+            }
+            wave_sync();
+        }
+        if (broken) { status = DMPP_G_INTERNAL; }
+        else {
+            if (lane == 0 && k < c.max_path) path[k] = start;
+            const int Lc = k + 1;
+            int keep = Lc;
+            if (Lc > c.max_path) { keep = c.max_path; status = DMPP_G_PATH_TRUNC; }
+            path_len = keep;
+            wave_sync();
+            for (int i = lane; i < keep / 2; i += DMPP_WAVE) {     // goal-first -> start-first
+                const int a0 = path[i], b0 = path[keep - 1 - i];
+                path[i] = b0; path[keep - 1 - i] = a0;
+            }
+        }
+    }
+    DBG_MARK(6)
+    R.status = status; R.n_exp = n_exp; R.n_push = n_push; R.n_rounds = n_rounds; R.path_cost = path_cost; R.path_len = path_len; R.digest = digest;
+    return R;
+#undef DBG_MARK
+}
+
+__device__ __forceinline__ void publish_search(GridOut& go, const SearchOut& R, int start, int goal)
+{
+    go.order_digest = R.digest; go.status = R.status; go.n_expanded = R.n_exp; go.n_pushed = R.n_push; go.n_rounds = R.n_rounds;
+    go.path_len = R.path_len; go.path_cost = R.path_cost; go.start_cell = start; go.goal_cell = goal;
+}
+
+#ifdef DMPP_DEBUG_SEARCH
+__device__ __forceinline__ void publish_debug(int32_t* path, int max_path, const long long* t, const int* cn, long long t_setup, long long t_total)
+{   // [iter, popped, jump_iters, diag_jobs, rounds, pop, closed, cand, jump, push, walk, loop+walk, setup, total] in units of 16 cycles
+    int32_t* dbg = path + max_path - 16;
+    dbg[0] = cn[0]; dbg[1] = cn[1]; dbg[2] = cn[2]; dbg[3] = cn[3]; dbg[4] = cn[4];
+    dbg[5] = (int)(t[0] >> 4); dbg[6] = (int)(t[1] >> 4); dbg[7] = (int)(t[2] >> 4); dbg[8] = (int)(t[3] >> 4); dbg[9] = (int)(t[4] >> 4);
+    dbg[10] = (int)(t[6] >> 4); dbg[11] = (int)((t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6]) >> 4); dbg[12] = (int)(t_setup >> 4); dbg[13] = (int)(t_total >> 4);
+    dbg[14] = 0; dbg[15] = 0;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------
+// The usual search kernel.  Dynamic LDS: the line metas of both views, then `budget` data words per view.
+//   overflow[scene] = 1 when the scene's non-zero words do not fit `budget` (k_search_gbm then runs it), else 0;
+//   need_max: running maximum of the words a scene needed (the host sizes the next launches from it).
+template <int K>
+__global__ void __launch_bounds__(kSearchBlock)
+k_search_lds(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
+             const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
+             int32_t* __restrict__ paths, GridOut* __restrict__ gout, int32_t* __restrict__ cost_out, int32_t* __restrict__ overflow,
+             int32_t* __restrict__ need_max)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ SearchLds L;
+    if ((int)blockIdx.x >= n_scenes) return;
+    const long long t_begin = clock64();
+    __builtin_amdgcn_s_setprio(3);             // one latency-bound wave per scene: issue ahead of the kernels that run beside it
+    const int scene = perm ? perm[blockIdx.x] : (int)blockIdx.x;      // heaviest scenes first (k_order) when they do not all fit at once
+    const int tid = threadIdx.x, lane = tid & (DMPP_WAVE - 1), wv = tid >> 6;
+    const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5, HW = H >> 5;
+    const SceneIn& si = in[scene];
+    // dynamic LDS layout
+    SparseView<K> vr, vc;
+    {
+        unsigned char* p = smem_raw;
+        if constexpr (K == 2) {
+            vr.meta = p; p += (size_t)H * 8; vc.meta = p; p += (size_t)W * 8;
+            vr.off2 = reinterpret_cast<uint32_t*>(p); p += (size_t)H * 4; vc.off2 = reinterpret_cast<uint32_t*>(p); p += (size_t)W * 4;
+        } else {
+            constexpr int mb = sparse_meta_bytes_per_line<K>();
+            vr.meta = p; p += (size_t)H * mb; vc.meta = p; p += (size_t)W * mb;
+            vr.off2 = nullptr; vc.off2 = nullptr;
+        }
+        p = reinterpret_cast<unsigned char*>(((uintptr_t)p + 15) & ~(uintptr_t)15);
+        vr.data = reinterpret_cast<uint32_t*>(p); vc.data = vr.data + budget;
+        vr.LW = WW; vr.NL = H; vc.LW = HW; vc.NL = W;
+    }
+    for (int i = tid; i < kClosedTab; i += kSearchBlock) L.c_tab[i] = 0;
+    const int need = build_sparse_views<K>(c, si, obs_now + si.obs_off, si.obs_n, vr, vc, budget, L.s_wave);
+    if (tid == 0) { atomicMax(need_max, need); overflow[scene] = need > budget ? 1 : 0; }
+    if (need > budget) return;                 // this scene goes to k_search_gbm (uniform over the block)
+    const int start = cell_of(c, si.grid_origin, si.loc.globalpoint.x, si.loc.globalpoint.y);
+    const int goal = cell_of(c, si.grid_origin, si.goal.x, si.goal.y);
+    const bool goal_blocked = cell_blocked(vr, goal % W, goal / W);       // the same in every wave
+    if (!goal_blocked && tid == 0) {                                      // the vehicle is where it is
+        sparse_clear_cell(vr, start / W, start % W);
+        sparse_clear_cell(vc, start % W, start / W);
+        L.o_ent[0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
+        L.o_f2[0] = (uint16_t)(hfun(start % W, start / W, goal % W, goal / W) >> 1);
+        L.o_run[0] = 0;
+    }
+    __syncthreads();
+    if (wv != 0) return;                       // set-up done: the search is wave 0's
+    const long long t_setup = clock64() - t_begin;
+    SearchOut R; R.status = DMPP_G_GOAL_BLOCKED; R.n_exp = 0; R.n_push = 0; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
+    int32_t* path = paths + (size_t)scene * c.max_path;
+#ifdef DMPP_DEBUG_SEARCH
+    long long dbg_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int dbg_c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+    if (!goal_blocked)
+        R = search_core(c, L, vr, vc, start, goal, order_cap, gclosed + (size_t)scene * (N >> 5), pinfo + (size_t)scene * N,
+                        orders ? orders + (size_t)scene * order_cap : nullptr, path, lane
+#ifdef DMPP_DEBUG_SEARCH
+                        , dbg_t, dbg_c
+#endif
+                        );
+#ifdef DMPP_DEBUG_SEARCH
+    if (lane == 0) publish_debug(path, c.max_path, dbg_t, dbg_c, t_setup, clock64() - t_begin);
+#endif
+    (void)t_setup;
+    if (lane == 0) {
+        cost_out[scene] = (int32_t)min((clock64() - t_begin) >> kOrderShift, (long long)(kOrderClasses - 1));   // launch-order key of the next tick (k_order)
+        publish_search(gout[scene], R, start, goal);
+    }
+}
+
+// The same search on the dense bitmaps k_rasterise wrote to HBM (row-major then column-major per scene), one u64 mask per
+// line in dynamic LDS.  Runs the scenes flagged in `overflow` (all scenes when it is null).
+__global__ void __launch_bounds__(kSearchBlock)
+k_search_gbm(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict__ overflow, const SceneIn* __restrict__ in,
+             uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders, int32_t* __restrict__ paths,
+             GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ SearchLds L;
+    const int scene = blockIdx.x;
+    if (scene >= n_scenes) return;
+    if (overflow && !overflow[scene]) return;
+    const long long t_begin = clock64();
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & (DMPP_WAVE - 1), wv = tid >> 6;
+    const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5, HW = H >> 5;
+    const SceneIn& si = in[scene];
+    uint64_t* nz_row = reinterpret_cast<uint64_t*>(smem_raw);
+    uint64_t* nz_col = nz_row + H;
+    uint32_t* bm = gbitmaps + (size_t)scene * 2 * (N >> 5);
+    uint32_t* bmT = bm + (N >> 5);
+    const int start = cell_of(c, si.grid_origin, si.loc.globalpoint.x, si.loc.globalpoint.y);
+    const int goal = cell_of(c, si.grid_origin, si.goal.x, si.goal.y);
+    const bool goal_blocked = ((bm[goal >> 5] >> (goal & 31)) & 1u) != 0;      // the same in every wave
+    if (!goal_blocked) {
+        if (tid == 0) {                                                     // the vehicle is where it is
+            const int sx = start % W, sy = start / W;
+            bm[start >> 5] &= ~(1u << (start & 31));
+            bmT[sx * HW + (sy >> 5)] &= ~(1u << (sy & 31));
+        }
+        __threadfence();
+        __syncthreads();
+        // line masks of both views (bit w = word w of the line is non-zero): one lane per line
+        for (int v = 0; v < 2; v++) {
+            const uint32_t* src = v ? bmT : bm;
+            uint64_t* nz = v ? nz_col : nz_row;
+            const int LW = v ? HW : WW, NL = v ? W : H;
+            for (int line = tid; line < NL; line += kSearchBlock) {
+                uint64_t msk = 0;
+                for (int w = 0; w < LW; w++) msk |= (uint64_t)min(src[line * LW + w], 1u) << w;
+                nz[line] = msk;
+            }
+        }
+        for (int i = tid; i < kClosedTab; i += kSearchBlock) L.c_tab[i] = 0;
+        if (tid == 0) {
+            L.o_ent[0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
+            L.o_f2[0] = (uint16_t)(hfun(start % W, start / W, goal % W, goal / W) >> 1);
+            L.o_run[0] = 0;
+        }
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    const long long t_setup = clock64() - t_begin;
+    SearchOut R; R.status = DMPP_G_GOAL_BLOCKED; R.n_exp = 0; R.n_push = 0; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
+    int32_t* path = paths + (size_t)scene * c.max_path;
+#ifdef DMPP_DEBUG_SEARCH
+    long long dbg_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int dbg_c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+    if (!goal_blocked) {
+        const DenseView Vrow{ bm, nz_row, WW, H }, Vcol{ bmT, nz_col, HW, W };
+        R = search_core(c, L, Vrow, Vcol, start, goal, order_cap, gclosed + (size_t)scene * (N >> 5), pinfo + (size_t)scene * N,
+                        orders ? orders + (size_t)scene * order_cap : nullptr, path, lane
+#ifdef DMPP_DEBUG_SEARCH
+                        , dbg_t, dbg_c
+#endif
+                        );
+    }
+#ifdef DMPP_DEBUG_SEARCH
+    if (lane == 0) publish_debug(path, c.max_path, dbg_t, dbg_c, t_setup, clock64() - t_begin);
+#endif
+    (void)t_setup;
+    if (lane == 0) {
+        cost_out[scene] = (int32_t)min((clock64() - t_begin) >> kOrderShift, (long long)(kOrderClasses - 1));
+        publish_search(gout[scene], R, start, goal);
+    }
+}
+
+// pp_get_grid: one scene's occupancy grid as bytes, produced by the SAME footprint code the search uses (so the tests see
+// what the search sees): the workgroup builds the sparse views and expands the row-major one; the column-major one is
+// checked against it cell by cell (mismatches counted in bad[0]).  bad[1] = 1 when the scene does not fit the LDS given.
+template <int K>
+__global__ void __launch_bounds__(kSearchBlock)
+k_export_grid(PlannerConfig c, int scene, int budget, const SceneIn* __restrict__ in, const ObPoint* __restrict__ obs_now,
+              uint8_t* __restrict__ out, int* __restrict__ bad)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ int s_wave[kSearchSetupWaves + 1];
+    const int tid = threadIdx.x;
+    const int W = c.grid_w, H = c.grid_h, WW = W >> 5, HW = H >> 5;
+    const SceneIn& si = in[scene];
+    SparseView<K> vr, vc;
+    {
+        unsigned char* p = smem_raw;
+        if constexpr (K == 2) {
+            vr.meta = p; p += (size_t)H * 8; vc.meta = p; p += (size_t)W * 8;
+            vr.off2 = reinterpret_cast<uint32_t*>(p); p += (size_t)H * 4; vc.off2 = reinterpret_cast<uint32_t*>(p); p += (size_t)W * 4;
+        } else {
+            constexpr int mb = sparse_meta_bytes_per_line<K>();
+            vr.meta = p; p += (size_t)H * mb; vc.meta = p; p += (size_t)W * mb;
+            vr.off2 = nullptr; vc.off2 = nullptr;
+        }
+        p = reinterpret_cast<unsigned char*>(((uintptr_t)p + 15) & ~(uintptr_t)15);
+        vr.data = reinterpret_cast<uint32_t*>(p); vc.data = vr.data + budget;
+        vr.LW = WW; vr.NL = H; vc.LW = HW; vc.NL = W;
+    }
+    const int need = build_sparse_views<K>(c, si, obs_now + si.obs_off, si.obs_n, vr, vc, budget, s_wave);
+    if (need > budget) { if (tid == 0) bad[1] = 1; return; }
+    int mism = 0;
+    for (int cell = tid; cell < W * H; cell += kSearchBlock) {
+        const int x = cell % W, y = cell / W;
+        const auto mr = vr.line(y); const auto mc = vc.line(x);
+        const uint32_t a = (vr.word(mr, x >> 5) >> (x & 31)) & 1u, b = (vc.word(mc, y >> 5) >> (y & 31)) & 1u;
+        out[cell] = (uint8_t)a;
+        mism += a != b;
+    }
+    if (mism) atomicAdd(&bad[0], mism);
+}
+
+}  // namespace dmpp

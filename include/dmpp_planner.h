@@ -46,7 +46,8 @@ typedef struct PlannerCaps {
 } PlannerCaps;
 
 /* kernels of one tick, in launch order; index into pp_get_kernel_ms */
-enum { PP_K_OBSTACLES = 0, PP_K_DECISION, PP_K_PLANNING, PP_K_RASTERISE, PP_K_SEARCH, PP_K_SCORE, PP_K_COUNT };
+enum { PP_K_OBSTACLES = 0, PP_K_DECISION, PP_K_PLANNING, PP_K_RASTERISE /* unused: the search rasterises for itself */, PP_K_SEARCH, PP_K_SCORE,
+       PP_K_FALLBACK /* k_rasterise + k_search_gbm for the scenes k_search_lds hands on */, PP_K_COUNT };
 /* device buffers addressable through pp_device_ptr (for RCCL scatter/gather by the caller) */
 enum { PP_BUF_SCENE_IN = 0, PP_BUF_LANE_POOL, PP_BUF_REF_POOL, PP_BUF_OBS_POOL, PP_BUF_MOT_POOL, PP_BUF_STATE,
        PP_BUF_PLAN_OUT, PP_BUF_GRID_OUT, PP_BUF_GRID, PP_BUF_PATH, PP_BUF_ORDER, PP_BUF_LANE_ATTR, PP_BUF_COUNT };
@@ -111,7 +112,7 @@ int  pp_sync(pp_handle h);
 int  pp_get_plan(pp_handle h, PlanOut* out, int n_scenes);
 int  pp_get_state(pp_handle h, SceneState* state, int n_scenes);
 int  pp_get_grid_out(pp_handle h, GridOut* out, int n_scenes);
-int  pp_get_grid(pp_handle h, int scene, uint8_t* grid);                 /* grid_w*grid_h bytes (expanded on demand: the tick keeps the grid bit-packed) */
+int  pp_get_grid(pp_handle h, int scene, uint8_t* grid);                 /* grid_w*grid_h bytes, 0 free / 1 occupied: rasterised on demand from the last tick's obstacle snapshot by the search's own footprint code */
 int  pp_get_order(pp_handle h, int scene, int32_t* order, int cap);      /* needs caps.order_cap > 0 */
 int  pp_get_path(pp_handle h, int scene, int32_t* path, int cap);
 /* DecisionOut.refpath published by the decision stage (Decision.cpp:195); PlanOut.dec.refpath_n points are valid */

@@ -329,7 +329,8 @@ def test_cpp_host_classes_example():
 
 
 def test_grid_2048_bitmap_in_hbm(dm, oracle):
-    """BASELINE configs[4] in small: 2048x2048 grid (512 KiB of bits > LDS: k_search<true> keeps the bitmap in HBM/L2)."""
+    """BASELINE configs[4] in small: 2048x2048 grid (64 line-mask bits per line: k_search_lds<2>; the sparse views need no more
+    LDS than at 512 x 512 - the stored words follow the obstacles, not the grid)."""
     cfg = dm.default_config(2048)
     sc = dm.gen_scenes(cfg, 21000, 6, 64, junction_every=3)
     pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=2, order_cap=1 << 20, mutate=lambda sc, t: move_ego(sc, 5) if t else None)
@@ -341,7 +342,7 @@ def test_grid_2048_bitmap_in_hbm(dm, oracle):
 
 
 def test_grid_1024_lds_optin(dm, oracle):
-    """1024x1024: 128 KiB bitmap + stack windows: needs the > 64 KiB dynamic-LDS opt-in (or falls back to the HBM bitmap)."""
+    """1024x1024: 32-bit line masks (k_search_lds<1>)."""
     cfg = dm.default_config(1024)
     sc = dm.gen_scenes(cfg, 22000, 6, 64, junction_every=0)
     pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=1)
@@ -807,3 +808,63 @@ def test_device_pointer_inputs_without_a_motion_pool(dm, oracle):
         bad = compare(pl.get_plan(), plan_o, "plan") + compare(pl.get_state(), st_o, "state") + compare(pl.get_grid_out(), gout_o, "grid")
         assert not bad, f"with_motion={with_motion}\n" + "\n".join(bad[:10])
         pl.close()
+
+
+@pytest.mark.parametrize("env,grid,n_obs", [({"DMPP_SEARCH_GBM": "1"}, 512, 64), ({"DMPP_LDS_BUDGET": "600"}, 512, 64),
+                                            ({"DMPP_LDS_BUDGET": "64"}, 128, 24), ({"DMPP_SEARCH_GBM": "1"}, 2048, 64)])
+def test_search_fallback_paths(dm, oracle, env, grid, n_obs):
+    """The dense-bitmap search (k_rasterise -> HBM -> k_search_gbm) that takes the scenes whose obstacle words do not fit the
+    LDS budget of a launch: forced for every scene (DMPP_SEARCH_GBM), and with a budget so small that only some scenes fit
+    (DMPP_LDS_BUDGET: both kernels work on the same batch).  Same results as the oracle either way."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        cfg = dm.default_config(grid)
+        n = 96 if grid < 2048 else 6
+        sc = dm.gen_scenes(cfg, 8800, n, n_obs, junction_every=4)
+        if "DMPP_LDS_BUDGET" in env:                      # a few sparse scenes that do fit next to the dense ones
+            keep = sc["scene_in"]["obs_n"].copy()
+            keep[::3] = max(n_obs // 8, 1)
+            sc["scene_in"]["obs_n"] = keep
+        pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=2, order_cap=4096 if grid < 2048 else 0,
+                             mutate=lambda sc_, t: move_ego(sc_, 4) if t else None)
+        for t, r in enumerate(res):
+            _assert_tick(r, f"{env} tick {t}")
+        kms = None
+        pl.set_profile(True)
+        pl.reset_kernel_ms()
+        pl.tick(sync=True)
+        kms = pl.kernel_ms()
+        assert kms["k_search_fallback"][1] == 1           # the fallback launches ran (and did real work in these cases)
+        if grid < 2048:
+            for s_ in (0, 1, 5):
+                st1 = sc["state"].copy()
+                go = None
+                for _ in range(2):
+                    _, go, grid_o, order_o, path_o = oracle.plan_tick_one(cfg, sc, s_, st1, order_cap=4096)
+                assert (pl.get_grid(s_) == grid_o).all(), s_
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_lds_budget_adapts(dm, oracle):
+    """The LDS budget of the search follows the scenes: sparse scenes first, then much denser ones in the same handle - the
+    first ticks after the change run the dense scenes through the fallback, later ones fit again; results equal the oracle's
+    throughout."""
+    cfg = dm.default_config(256)
+    n = 64
+    pl = dm.Planner(cfg, max_scenes=n, max_obs_total=n * 200)
+    for n_obs, seed in ((6, 100), (200, 200), (6, 300)):
+        sc = dm.gen_scenes(cfg, seed, n, n_obs, junction_every=0)
+        st_o = sc["state"].copy()
+        pl.set_scenes(sc)
+        pl.set_state(sc["state"])
+        for t in range(5):
+            pl.tick(sync=True)
+            plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st_o, n_threads=8, want_grid=True)
+            bad = compare(pl.get_grid_out(), gout_o, "grid") + compare(pl.get_state(), st_o, "state")
+            assert not bad, f"{n_obs} obstacles, tick {t}\n" + "\n".join(bad[:10])

@@ -89,51 +89,55 @@ template <class M> struct LineM { M mask; uint32_t off; };
 // Sparse view in LDS: only the words flagged in `mask` are stored, in word order, from data[off].
 //   K = 0: LW <= 16, one u32 per line (mask | off << 16);  K = 1: LW <= 32, uint2 {mask, off};
 //   K = 2: LW <= 64, u64 mask[] and u32 off[].
+#define DMPP_LDS __attribute__((address_space(3)))
 template <int K>
 struct SparseView {
     using M = std::conditional_t<K == 2, uint64_t, uint32_t>;
-    uint32_t* data; void* meta; uint32_t* off2; int LW, NL;
+    // address_space(3): the compiler must know these are LDS (ds_read / ds_or), not generic pointers (flat_load)
+    DMPP_LDS uint32_t* data; DMPP_LDS unsigned char* meta; DMPP_LDS uint32_t* off2; int LW, NL;
 
     __device__ __forceinline__ LineM<M> line(int l) const
     {
         LineM<M> r; r.mask = 0; r.off = kLineOutside;
         if ((unsigned)l < (unsigned)NL) {
-            if constexpr (K == 0) { const uint32_t v = reinterpret_cast<const uint32_t*>(meta)[l]; r.mask = v & 0xFFFFu; r.off = v >> 16; }
-            else if constexpr (K == 1) { const uint2 v = reinterpret_cast<const uint2*>(meta)[l]; r.mask = v.x; r.off = v.y; }
-            else { r.mask = reinterpret_cast<const uint64_t*>(meta)[l]; r.off = off2[l]; }
+            if constexpr (K == 0) { const uint32_t v = ((DMPP_LDS const uint32_t*)meta)[l]; r.mask = v & 0xFFFFu; r.off = v >> 16; }
+            else if constexpr (K == 1) { r.mask = ((DMPP_LDS const uint32_t*)meta)[2 * l]; r.off = ((DMPP_LDS const uint32_t*)meta)[2 * l + 1]; }
+            else { r.mask = ((DMPP_LDS const uint64_t*)meta)[l]; r.off = off2[l]; }
         }
         return r;
     }
     __device__ __forceinline__ uint32_t word(const LineM<M>& m, int w) const
-    {
-        if (m.off == kLineOutside || (unsigned)w >= (unsigned)LW) return 0xFFFFFFFFu;
-        const M bit = (M)1 << w;
-        if (!(m.mask & bit)) return 0u;
-        return data[m.off + popc_m((M)(m.mask & (bit - 1)))];
+    {   // branch-free: one unconditional LDS read (index 0 when the word is not stored), the rest are selects
+        const bool outside = m.off == kLineOutside || (unsigned)w >= (unsigned)LW;
+        const M bit = (M)1 << (w & (int)(8 * sizeof(M) - 1));
+        const bool present = !outside && (m.mask & bit) != 0;
+        const uint32_t idx = present ? m.off + (uint32_t)popc_m((M)(m.mask & (bit - 1))) : 0u;
+        const uint32_t v = data[idx];
+        return outside ? 0xFFFFFFFFu : (present ? v : 0u);
     }
     // ---- construction (setup waves) ----
     __device__ __forceinline__ void clear_line(int l) const
     {
-        if constexpr (K == 0) reinterpret_cast<uint32_t*>(meta)[l] = 0;
-        else if constexpr (K == 1) reinterpret_cast<uint2*>(meta)[l] = make_uint2(0u, 0u);
-        else { reinterpret_cast<uint64_t*>(meta)[l] = 0; off2[l] = 0; }
+        if constexpr (K == 0) ((DMPP_LDS uint32_t*)meta)[l] = 0;
+        else if constexpr (K == 1) { ((DMPP_LDS uint32_t*)meta)[2 * l] = 0; ((DMPP_LDS uint32_t*)meta)[2 * l + 1] = 0; }
+        else { ((DMPP_LDS uint64_t*)meta)[l] = 0; off2[l] = 0; }
     }
     __device__ __forceinline__ void or_mask(int l, M bits) const
     {
-        if constexpr (K == 0) atomicOr(&reinterpret_cast<uint32_t*>(meta)[l], (uint32_t)bits);
-        else if constexpr (K == 1) atomicOr(&reinterpret_cast<uint2*>(meta)[l].x, (uint32_t)bits);
-        else atomicOr(reinterpret_cast<unsigned long long*>(&reinterpret_cast<uint64_t*>(meta)[l]), (unsigned long long)bits);
+        if constexpr (K == 0) __hip_atomic_fetch_or(&((DMPP_LDS uint32_t*)meta)[l], (uint32_t)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else if constexpr (K == 1) __hip_atomic_fetch_or(&((DMPP_LDS uint32_t*)meta)[2 * l], (uint32_t)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_or(&((DMPP_LDS uint64_t*)meta)[l], (uint64_t)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __device__ __forceinline__ M mask_of(int l) const
     {
-        if constexpr (K == 0) return reinterpret_cast<const uint32_t*>(meta)[l] & 0xFFFFu;
-        else if constexpr (K == 1) return reinterpret_cast<const uint2*>(meta)[l].x;
-        else return reinterpret_cast<const uint64_t*>(meta)[l];
+        if constexpr (K == 0) return ((DMPP_LDS const uint32_t*)meta)[l] & 0xFFFFu;
+        else if constexpr (K == 1) return ((DMPP_LDS const uint32_t*)meta)[2 * l];
+        else return ((DMPP_LDS const uint64_t*)meta)[l];
     }
     __device__ __forceinline__ void set_off(int l, uint32_t off) const
     {
-        if constexpr (K == 0) reinterpret_cast<uint32_t*>(meta)[l] |= off << 16;
-        else if constexpr (K == 1) reinterpret_cast<uint2*>(meta)[l].y = off;
+        if constexpr (K == 0) ((DMPP_LDS uint32_t*)meta)[l] |= off << 16;
+        else if constexpr (K == 1) ((DMPP_LDS uint32_t*)meta)[2 * l + 1] = off;
         else off2[l] = off;
     }
 };
@@ -142,7 +146,7 @@ template <int K> __host__ __device__ constexpr int sparse_meta_bytes_per_line() 
 // Dense view: the bitmap of k_rasterise in HBM, one u64 mask per line in LDS (bit w = word w is non-zero).
 struct DenseView {
     using M = uint64_t;
-    const uint32_t* base; const uint64_t* nz; int LW, NL;
+    const uint32_t* base; DMPP_LDS const uint64_t* nz; int LW, NL;
     __device__ __forceinline__ LineM<M> line(int l) const
     {
         LineM<M> r; r.mask = 0; r.off = kLineOutside;
@@ -250,23 +254,32 @@ __device__ __forceinline__ Footprint footprint_of(const PlannerConfig& c, Global
 
 // Exact run [a, b] of indices i in [lo, hi] with  du(i)^2 + dv2 <= R2,  du(i) = (org + (i + 0.5) * cell) - ou.
 // `ic` = floor((ou - org) / cell), the index whose centre is nearest to ou (or next to it).  Returns false when empty.
+// The true indices form ONE run (see above), so an end is certified by two evaluations: true at the end, false just
+// outside.  The sqrt estimate passes that test nearly always; when it does not, the ends are walked to their place.
 __device__ __forceinline__ bool exact_span(double ou, double org, double cell, double inv_cell, double dv2, double R2, int ic,
                                            int lo, int hi, int& a, int& b)
 {
+    if (dv2 > R2) return false;                            // du*du >= 0: no index can satisfy the predicate
     auto pred = [&](int i) { const double du = (org + ((double)i + 0.5) * cell) - ou; return du * du + dv2 <= R2; };
-    int t;
-    if (pred(ic)) t = ic; else if (pred(ic - 1)) t = ic - 1; else if (pred(ic + 1)) t = ic + 1; else return false;
-    if (t < lo) { if (!pred(lo)) return false; }         // the run contains t: it reaches the window only through lo
-    if (t > hi) { if (!pred(hi)) return false; }
-    const double half = sqrt(fmax(R2 - dv2, 0.0));
-    a = clampi((int)ceil((ou - half - org) * inv_cell - 0.5), lo, max(min(t, hi), lo));
-    b = clampi((int)floor((ou + half - org) * inv_cell - 0.5), min(max(t, lo), hi), hi);
-    while (a > lo && pred(a - 1)) a--;
-    while (a <= hi && !pred(a)) a++;
-    if (a > hi) return false;
-    while (b < hi && pred(b + 1)) b++;
-    while (b >= a && !pred(b)) b--;
-    return b >= a;
+    const double half = sqrt(R2 - dv2);
+    a = (int)ceil((ou - half - org) * inv_cell - 0.5);
+    b = (int)floor((ou + half - org) * inv_cell - 0.5);
+    if (!(a <= b && pred(a) && !pred(a - 1) && pred(b) && !pred(b + 1))) {
+        // rare: an estimate one off, or an empty run.  Find a true index next to the centre, then walk both ends.
+        int t;
+        if (pred(ic)) t = ic; else if (pred(ic - 1)) t = ic - 1; else if (pred(ic + 1)) t = ic + 1; else return false;
+        a = min(a, t); b = max(b, t);
+#pragma nounroll
+        for (int g = 0; g < 4096 && pred(a - 1); g++) a--;
+#pragma nounroll
+        for (int g = 0; g < 4096 && !pred(a); g++) a++;
+#pragma nounroll
+        for (int g = 0; g < 4096 && pred(b + 1); g++) b++;
+#pragma nounroll
+        for (int g = 0; g < 4096 && !pred(b); g++) b--;
+    }
+    a = max(a, lo); b = min(b, hi);
+    return a <= b;
 }
 
 // bits [p0, p1] of a line as (word, mask) pieces
@@ -297,31 +310,82 @@ __device__ __forceinline__ int block_excl_scan(int v, int tid, int* s_wave /* [k
 }
 
 // Builds both sparse views of a scene from its obstacle list.  All kSearchBlock threads; returns the words the larger view
-// needs (> budget: nothing was filled, the views are unusable).  The masks come from the obstacles' bounding boxes (a
-// superset: a few stored words stay zero), the bits from the exact spans.
+// needs (> budget: nothing was filled, the views are unusable).
+//   pass 1: which words of which lines the footprints touch (exact spans: the line masks say exactly which words are non-zero);
+//   offsets: exclusive prefix sum of the word counts over the lines;  pass 2: the same spans again, OR-ed into the words.
+// A wave owns the obstacles wv, wv + 4, ...; it computes 64 footprints at once (one per lane: the divisions are paid once
+// per obstacle, not per line) and then walks them, lanes 0..31 on a footprint's rows and lanes 32..63 on its columns.
 template <int K>
 __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m,
-                                         const SparseView<K>& vr, const SparseView<K>& vc, int budget, int* s_wave)
+                                                  const SparseView<K>& vr, const SparseView<K>& vc, int budget, int* s_wave,
+                                                  long long* tmark = nullptr)
 {
     using M = typename SparseView<K>::M;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int tm_i = 0;
+    auto mark = [&]() { if (tmark) tmark[tm_i++] = clock64(); };
+    mark();
     const int W = c.grid_w, H = c.grid_h;
     const bool colhalf = lane >= 32;                        // lanes 0..31: rows of the footprint, 32..63: its columns
     const int l32 = lane & 31;
+    const double inv_cell = 1.0 / c.cell;
+    const double org_u = colhalf ? si.grid_origin.y : si.grid_origin.x, org_v = colhalf ? si.grid_origin.x : si.grid_origin.y;
     for (int l = tid; l < H; l += kSearchBlock) vr.clear_line(l);
     for (int l = tid; l < W; l += kSearchBlock) vc.clear_line(l);
     __syncthreads();
-    // ---- pass 1: which words of which lines a footprint's box touches ----
-    for (int j = wv; j < m; j += kSearchSetupWaves) {
-        const Footprint f = footprint_of(c, si.grid_origin, obs[j], W, H);
-        if (f.ix1 < f.ix0 || f.iy1 < f.iy0) continue;
-        const int l0 = colhalf ? f.ix0 : f.iy0, l1 = colhalf ? f.ix1 : f.iy1;
-        const int p0 = colhalf ? f.iy0 : f.ix0, p1 = colhalf ? f.iy1 : f.ix1;
-        const int wa = p0 >> 5, wb = p1 >> 5;
-        const M bits = (M)((wb - wa >= (int)(8 * sizeof(M)) - 1) ? ~(M)0 : ((((M)2) << (wb - wa)) - (M)1)) << wa;
-        for (int l = l0 + l32; l <= l1; l += 32) { if (colhalf) vc.or_mask(l, bits); else vr.or_mask(l, bits); }
+
+    struct Lanes { Footprint f; int icx, icy; bool any; };
+    auto footprints_of_chunk = [&](int base) {              // this lane's obstacle of the chunk that starts at `base`
+        Lanes q; q.any = false; q.icx = q.icy = 0;
+        q.f.ox = q.f.oy = q.f.R2 = 0; q.f.ix0 = q.f.iy0 = 0; q.f.ix1 = q.f.iy1 = -1;
+        const int j = base + wv + kSearchSetupWaves * lane;
+        if (j < m) {
+            q.f = footprint_of(c, si.grid_origin, obs[j], W, H);
+            q.any = q.f.ix1 >= q.f.ix0 && q.f.iy1 >= q.f.iy0;
+            q.icx = (int)floor((q.f.ox - si.grid_origin.x) / c.cell);
+            q.icy = (int)floor((q.f.oy - si.grid_origin.y) / c.cell);
+        }
+        return q;
+    };
+    auto bcast_d = [](double v, int src) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    };
+    // fn(ou, ov, R2, ic, l0, l1, lo, hi): one footprint seen from this lane's half (u along the lines, v across them)
+    auto walk = [&](const Lanes& mine, int base, auto&& fn) {
+        const int left = m - base - wv;
+        const int cnt = left <= 0 ? 0 : min(DMPP_WAVE, (left + kSearchSetupWaves - 1) / kSearchSetupWaves);
+        const unsigned long long anym = __ballot(mine.any);
+        for (int q = 0; q < cnt; q++) {
+            if (!((anym >> q) & 1ull)) continue;
+            const double fx = bcast_d(mine.f.ox, q), fy = bcast_d(mine.f.oy, q), R2 = bcast_d(mine.f.R2, q);
+            const int ix0 = __builtin_amdgcn_readlane(mine.f.ix0, q), ix1 = __builtin_amdgcn_readlane(mine.f.ix1, q);
+            const int iy0 = __builtin_amdgcn_readlane(mine.f.iy0, q), iy1 = __builtin_amdgcn_readlane(mine.f.iy1, q);
+            const int icx = __builtin_amdgcn_readlane(mine.icx, q), icy = __builtin_amdgcn_readlane(mine.icy, q);
+            fn(colhalf ? fy : fx, colhalf ? fx : fy, R2, colhalf ? icy : icx, colhalf ? ix0 : iy0, colhalf ? ix1 : iy1,
+               colhalf ? iy0 : ix0, colhalf ? iy1 : ix1);
+        }
+    };
+    const int chunk = kSearchSetupWaves * DMPP_WAVE;
+    mark();
+    const Lanes first = footprints_of_chunk(0);             // kept in registers for pass 2 (the usual case: <= 256 obstacles)
+    mark();
+    // ---- pass 1 ----
+    for (int base = 0; base < m; base += chunk) {
+        const Lanes cur = base == 0 ? first : footprints_of_chunk(base);
+        walk(cur, base, [&](double ou, double ov, double R2, int ic, int l0, int l1, int lo, int hi) {
+            for (int l = l0 + l32; l <= l1; l += 32) {
+                const double dv = (org_v + ((double)l + 0.5) * c.cell) - ov;
+                int a, b;
+                if (!exact_span(ou, org_u, c.cell, inv_cell, dv * dv, R2, ic, lo, hi, a, b)) continue;
+                const int wa = a >> 5, wb = b >> 5;
+                const M bits = (M)((((M)2) << (wb - wa)) - (M)1) << wa;
+                if (colhalf) vc.or_mask(l, bits); else vr.or_mask(l, bits);
+            }
+        });
     }
     __syncthreads();
+    mark();
     // ---- offsets: exclusive prefix sum of the word counts over the lines, per view ----
     auto place = [&](const SparseView<K>& vw) {
         const int NL = vw.NL, per = (NL + kSearchBlock - 1) / kSearchBlock;
@@ -336,32 +400,30 @@ __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const 
     };
     const int total_r = place(vr), total_c = place(vc);
     const int need = max(total_r, total_c);
+    mark();
     if (need > budget) return need;
     for (int i = tid; i < total_r; i += kSearchBlock) vr.data[i] = 0;
     for (int i = tid; i < total_c; i += kSearchBlock) vc.data[i] = 0;
     __syncthreads();
+    mark();
     // ---- pass 2: the exact spans ----
-    const double inv_cell = 1.0 / c.cell;
-    for (int j = wv; j < m; j += kSearchSetupWaves) {
-        const Footprint f = footprint_of(c, si.grid_origin, obs[j], W, H);
-        if (f.ix1 < f.ix0 || f.iy1 < f.iy0) continue;
-        const double ou = colhalf ? f.oy : f.ox, ov = colhalf ? f.ox : f.oy;                 // along the line / across the lines
-        const double org_u = colhalf ? si.grid_origin.y : si.grid_origin.x, org_v = colhalf ? si.grid_origin.x : si.grid_origin.y;
-        const int ic = (int)floor((ou - org_u) / c.cell);
-        const int l0 = colhalf ? f.ix0 : f.iy0, l1 = colhalf ? f.ix1 : f.iy1;
-        const int lo = colhalf ? f.iy0 : f.ix0, hi = colhalf ? f.iy1 : f.ix1;
-        const SparseView<K> vw = colhalf ? vc : vr;         // by value: per-lane field selects, no stack object
-        for (int l = l0 + l32; l <= l1; l += 32) {
-            const double dv = (org_v + ((double)l + 0.5) * c.cell) - ov;
-            int a, b;
-            if (!exact_span(ou, org_u, c.cell, inv_cell, dv * dv, f.R2, ic, lo, hi, a, b)) continue;
-            const LineM<M> lm = vw.line(l);
-            for_words(a, b, [&](int w, uint32_t bits) {
-                atomicOr(&vw.data[lm.off + popc_m((M)(lm.mask & ((((M)1) << w) - (M)1)))], bits);
-            });
-        }
+    const SparseView<K> vw = colhalf ? vc : vr;             // by value: per-lane field selects, no stack object
+    for (int base = 0; base < m; base += chunk) {
+        const Lanes cur = base == 0 ? first : footprints_of_chunk(base);
+        walk(cur, base, [&](double ou, double ov, double R2, int ic, int l0, int l1, int lo, int hi) {
+            for (int l = l0 + l32; l <= l1; l += 32) {
+                const double dv = (org_v + ((double)l + 0.5) * c.cell) - ov;
+                int a, b;
+                if (!exact_span(ou, org_u, c.cell, inv_cell, dv * dv, R2, ic, lo, hi, a, b)) continue;
+                const LineM<M> lm = vw.line(l);
+                for_words(a, b, [&](int w, uint32_t bits) {
+                    __hip_atomic_fetch_or(&vw.data[lm.off + popc_m((M)(lm.mask & ((((M)1) << w) - (M)1)))], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                });
+            }
+        });
     }
     __syncthreads();
+    mark();
     return need;
 }
 
@@ -382,13 +444,36 @@ struct SearchLds {                               // the static LDS of a searchin
     uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
     uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
     uint16_t c_info[kClosedTab];    // arriving direction | run length << 4 of the cell in the same slot
-    int dc_owner[kMaxDiag];         // the (node, s) lanes of the diagonal jumps of the current step
-    uint32_t sj_job[kDiagGroup];    // its straight jumps (<= 8), packed
+    uint32_t job[kMaxDiag + 8];     // the jumps of the current step, x | y << 12 | s << 24: diagonal ones (<= 16), then straight ones (<= 8)
     int s_wave[kSearchSetupWaves + 1];
     int s_flag;
 };
 
 struct SearchOut { int status, n_exp, n_push, n_rounds, path_cost, path_len; uint64_t digest; };
+
+// Squeezes the dead slots out of the open list, keeping the push order (ballot + prefix popcount); the slots that fall free
+// are marked dead again (the pop relies on 0xFFFF at and beyond n_open).  Returns the new n_open.
+__device__ __forceinline__ int squeeze_open(SearchLds& L, int n_open, int lane)
+{
+    int w = 0;
+    for (int q0 = 0; q0 < n_open; q0 += DMPP_WAVE) {
+        const int i = q0 + lane;
+        uint32_t f2 = 0xFFFFu, ee = 0; uint16_t rr = 0;
+        if (i < n_open) { f2 = L.o_f2[i]; ee = L.o_ent[i]; rr = L.o_run[i]; }
+        const bool alive = f2 != 0xFFFFu;
+        const unsigned long long am = __ballot(alive);
+        wave_order();
+        if (alive) {
+            const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+            L.o_f2[w + r] = (uint16_t)f2; L.o_ent[w + r] = ee; L.o_run[w + r] = rr;
+        }
+        w += __popcll(am);
+        wave_order();
+    }
+    for (int i = w + lane; i < n_open; i += DMPP_WAVE) L.o_f2[i] = 0xFFFFu;
+    wave_order();
+    return w;
+}
 
 // The search proper, one wave.  Vrow / Vcol: the two views; closed / pin: this scene's spill area in HBM.
 template <class V>
@@ -418,65 +503,63 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
     const int s = lane & 7;
     const int sdx = (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0);
     const int sdy = (s >= 1 && s <= 3) ? 1 : ((s >= 5) ? -1 : 0);
+    // ---- lane roles, fixed for the whole search ----
+    // (node, s) lanes 0..31: the eight directions of each of the (<= 4) nodes of a step; lanes with s == 0 also stand for
+    // their node in the closed-set test.
+    const int node = (lane >> 3) & 3;
+    // scan lanes of the jumps: lanes 0..27 the horizontal scans of (diagonal job j, cell k) = (lane / 7, lane % 7 + 1), lanes
+    // 28..55 the vertical ones, lanes 56..63 the straight jumps (<= 8) - four diagonal jumps and every straight jump of a
+    // step in ONE round.  Cell 8 of a diagonal needs no scan: whatever one would find, the jump ends there.
+    const bool is_dscan = lane < 56, bhv = lane >= 28;
+    const int bq = bhv ? lane - 28 : lane;
+    const int bj = is_dscan ? bq / 7 : 0, bk = is_dscan ? bq % 7 + 1 : 0;
+    // cell-test lanes of the diagonal jumps: lanes 0..31 = (job, cell 1..8)
+    const int aj = node, ak = (lane & 7) + 1;
     long long guard = 16ll * N + 1024;                 // every iteration pops an entry; entries <= 8 per closed cell
+    int steps = 0;
     while (status < 0) {
         if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
+        // The kernel ends with its longest search, and several searching waves share a SIMD: a search that has already run
+        // long issues ahead of the fresh ones (and of the set-up waves, which run at the lowest priority)
+        if (steps == 24) __builtin_amdgcn_s_setprio(2);
+        if (steps == 56) __builtin_amdgcn_s_setprio(3);
+        steps++;
 #ifdef DMPP_DEBUG_SEARCH
         dbg_c[0]++;
 #endif
         if (live == 0) { status = DMPP_G_NO_PATH; break; }
         // ---- pop: up to 4 entries of the smallest f, the latest pushes first ----
         // (1) squeeze the dead slots out when they outnumber the live ones: the scans below stay short
-        if ((n_open - live > 64 && n_open > 2 * live)) {
-            int w = 0;
-            for (int q0 = 0; q0 < n_open; q0 += DMPP_WAVE) {
-                const int i = q0 + lane;
-                uint32_t f2 = 0xFFFFu, ee = 0; uint16_t rr = 0;
-                if (i < n_open) { f2 = L.o_f2[i]; ee = L.o_ent[i]; rr = L.o_run[i]; }
-                const bool alive = f2 != 0xFFFFu;
-                const unsigned long long am = __ballot(alive);
-                wave_order();
-                if (alive) {
-                    const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
-                    L.o_f2[w + r] = (uint16_t)f2; L.o_ent[w + r] = ee; L.o_run[w + r] = rr;
-                }
-                w += __popcll(am);
-                wave_order();
-            }
-            n_open = w;
-        }
-        // (2) the first 256 slots are cached in registers: one LDS pass serves both the minimum and the ties
-        uint32_t v0 = 0xFFFFu, v1 = 0xFFFFu, v2 = 0xFFFFu, v3 = 0xFFFFu;
-        if (lane < n_open) v0 = L.o_f2[lane];
-        if (lane + 64 < n_open) v1 = L.o_f2[lane + 64];
-        if (lane + 128 < n_open) v2 = L.o_f2[lane + 128];
-        if (lane + 192 < n_open) v3 = L.o_f2[lane + 192];
-        uint32_t key = min(min(v0, v1), min(v2, v3));
-        for (int i = lane + 256; i < n_open; i += DMPP_WAVE) { const uint32_t f2 = L.o_f2[i]; if (f2 < key) key = f2; }
-        const uint32_t fmin2 = wave_min_u32(key);
+        if ((n_open - live > 64 && n_open > 2 * live)) n_open = squeeze_open(L, n_open, lane);
+        // (2) the keys, 64 slots per register; slots at and beyond n_open always hold 0xFFFF, so nothing is range-checked
+        const uint32_t v0 = L.o_f2[lane], v1 = L.o_f2[lane + 64], v2 = L.o_f2[lane + 128], v3 = L.o_f2[lane + 192];
+        uint32_t v4 = 0xFFFFu, v5 = 0xFFFFu, v6 = 0xFFFFu, v7 = 0xFFFFu;
+        const bool upper = n_open > 256;
+        if (upper) { v4 = L.o_f2[lane + 256]; v5 = L.o_f2[lane + 320]; v6 = L.o_f2[lane + 384]; v7 = L.o_f2[lane + 448]; }
+        const uint32_t fmin2 = wave_min_u32(min(min(min(v0, v1), min(v2, v3)), min(min(v4, v5), min(v6, v7))));
         if (fmin2 == 0xFFFFu) { status = DMPP_G_INTERNAL; break; }
         const int f = (int)fmin2 << 1;
         int nt = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
-        for (int c0 = ((n_open - 1) >> 6) << 6; c0 >= 0 && nt < DMPP_JPS_BATCH; c0 -= DMPP_WAVE) {
-            const int i = c0 + lane;
-            bool tie;
-            if (c0 == 0) tie = v0 == fmin2; else if (c0 == 64) tie = v1 == fmin2; else if (c0 == 128) tie = v2 == fmin2;
-            else if (c0 == 192) tie = v3 == fmin2; else tie = i < n_open && L.o_f2[i] == fmin2;
-            unsigned long long tm = __ballot(tie);
-            while (tm && nt < DMPP_JPS_BATCH) {
-                const int Lm = 63 - __clzll((long long)tm);
-                tm &= ~(1ull << Lm);
-                const int idx = c0 + Lm;
-                if (nt == 0) i0 = idx; else if (nt == 1) i1 = idx; else if (nt == 2) i2 = idx; else i3 = idx;
-                nt++;
-            }
+#define DMPP_TAKE(vreg, base)                                                                        \
+        {                                                                                            \
+            unsigned long long tm = __ballot((vreg) == fmin2);                                       \
+            while (tm && nt < DMPP_JPS_BATCH) {                                                      \
+                const int b = 63 - __clzll((long long)tm);                                           \
+                tm &= ~(1ull << b);                                                                  \
+                const int idx = (base) + b;                                                          \
+                if (nt == 0) i0 = idx; else if (nt == 1) i1 = idx; else if (nt == 2) i2 = idx; else i3 = idx; \
+                nt++;                                                                                \
+            }                                                                                        \
         }
-        const int myi = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : i3;
-        const bool have = lane < nt;
-        uint32_t e = 0; int run_in = 0;
-        if (have) { e = L.o_ent[myi]; run_in = L.o_run[myi]; }
+        if (upper) { DMPP_TAKE(v7, 448) DMPP_TAKE(v6, 384) DMPP_TAKE(v5, 320) DMPP_TAKE(v4, 256) }
+        DMPP_TAKE(v3, 192) DMPP_TAKE(v2, 128) DMPP_TAKE(v1, 64) DMPP_TAKE(v0, 0)
+#undef DMPP_TAKE
+        // every (node, s) lane reads its node's entry itself (a broadcast read): no cross-lane traffic afterwards
+        const int myi = node == 0 ? i0 : node == 1 ? i1 : node == 2 ? i2 : i3;
+        const bool have = lane < 32 && node < nt;
+        const uint32_t e = L.o_ent[myi]; const int run_in = L.o_run[myi];
         wave_order();
-        if (have) L.o_f2[myi] = 0xFFFFu;
+        if (have && s == 0) L.o_f2[myi] = 0xFFFFu;
         live -= nt;
         if (i0 == n_open - 1) n_open--;
         const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu), d = (int)(e >> 24);
@@ -485,12 +568,29 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
 #ifdef DMPP_DEBUG_SEARCH
         dbg_c[1] += nt;
 #endif
-        // ---- closed?  duplicates inside the batch: the earlier one wins; then the closed set ----
-        bool valid = have;
+        // ---- successor rules, evaluated for every popped entry before its closed-set test (the reads overlap the hash probe) ----
+        const int gcur = f - hfun(x, y, gx, gy);
+        bool jump0, diag0;
         {
-            const int c0_ = __builtin_amdgcn_readlane(cell, 0), c1_ = __builtin_amdgcn_readlane(cell, 1), c2_ = __builtin_amdgcn_readlane(cell, 2);
-            if ((lane == 1 && cell == c0_) || (lane == 2 && (cell == c0_ || cell == c1_)) ||
-                (lane == 3 && (cell == c0_ || cell == c1_ || cell == c2_))) valid = false;
+            const int dd = d & 7;
+            const int ddx = (dd == 0 || dd == 1 || dd == 7) ? 1 : ((dd >= 3 && dd <= 5) ? -1 : 0);
+            const int ddy = (dd >= 1 && dd <= 3) ? 1 : ((dd >= 5) ? -1 : 0);
+            const int rel = (s - d) & 7;
+            const bool is_start = d == 8, d_odd = (d & 1) != 0 && !is_start, d_even = !d_odd && !is_start;
+            jump0 = (is_start && (s & 1) == 0) || (d_even && rel == 0) || (d_odd && (rel == 1 || rel == 7));
+            const bool plain = (is_start && (s & 1) != 0) || (d_odd && rel == 0);
+            const bool sided = (d_even && (rel == 1 || rel == 7)) || (d_odd && (rel == 2 || rel == 6));
+            const int px = d_odd ? (sdx - ddx) / 2 : sdx - ddx, py = d_odd ? (sdy - ddy) / 2 : sdy - ddy;
+            const bool t_blk = cell_blocked(Vrow, x + sdx, y + sdy);
+            const bool side_blk = cell_blocked(Vrow, x + px, y + py);
+            diag0 = !t_blk && (plain || (sided && side_blk));
+        }
+        // ---- closed?  duplicates inside the batch: the earlier one wins; then the closed set (lanes with s == 0) ----
+        bool valid = have && s == 0;
+        {
+            const int c0_ = __builtin_amdgcn_readlane(cell, 0), c1_ = __builtin_amdgcn_readlane(cell, 8), c2_ = __builtin_amdgcn_readlane(cell, 16);
+            if ((node == 1 && cell == c0_) || (node == 2 && (cell == c0_ || cell == c1_)) ||
+                (node == 3 && (cell == c0_ || cell == c1_ || cell == c2_))) valid = false;
         }
         if (n_exp + DMPP_JPS_BATCH <= kClosedMax) {
             if (valid) {
@@ -525,19 +625,20 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
                 if ((old >> (cell & 31)) & 1u) valid = false;
             }
         }
-        // the goal, or the entry that reaches the expansion limit, ends the search at once
-        unsigned vm = (unsigned)__ballot(valid) & 0xFu;
-        {
-            const int nvb = __popc(vm & ((1u << lane) - 1u));
-            const unsigned stop = (unsigned)__ballot(valid && (cell == goal || n_exp + nvb + 1 >= c.max_expansions)) & 0xFu;
+        // node mask from the s == 0 lanes (bits 0, 8, 16, 24 of a ballot -> bits 0..3)
+        auto nodes_of = [](unsigned long long bm) { const unsigned b = (unsigned)bm; return (b & 1u) | ((b >> 7) & 2u) | ((b >> 14) & 4u) | ((b >> 21) & 8u); };
+        unsigned vm = nodes_of(__ballot(valid));
+        {   // the goal, or the entry that reaches the expansion limit, ends the search at once
+            const int nvb = __popc(vm & ((1u << node) - 1u));
+            const unsigned stop = nodes_of(__ballot(valid && (cell == goal || n_exp + nvb + 1 >= c.max_expansions)));
             if (stop) {
                 const int last = __ffs((int)stop) - 1;
-                if (lane > last) valid = false;
-                vm = (unsigned)__ballot(valid) & 0xFu;
+                if (node > last) valid = false;
+                vm = nodes_of(__ballot(valid));
             }
         }
         if (valid) {
-            const int seq = n_exp + __popc(vm & ((1u << lane) - 1u));
+            const int seq = n_exp + __popc(vm & ((1u << node) - 1u));
             if (!hash_complete) pin[cell] = (uint16_t)(d | (run_in << 4));
             if (order && seq < order_cap) order[seq] = cell;
             digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell);
@@ -548,90 +649,72 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
         if (n_exp >= c.max_expansions) { status = DMPP_G_LIMIT; break; }
         if (vm == 0) continue;
         DBG_MARK(1)
-        // ---- successors: lane = node * 8 + s for the (<= 4) batch nodes ----
-        const int node = lane >> 3;
-        const int nx0 = __shfl(x, node, 64), ny0 = __shfl(y, node, 64), nd = __shfl(d, node, 64);
         const bool nvalid = lane < 32 && ((vm >> node) & 1u);
-        const int gcur = f - hfun(nx0, ny0, gx, gy);
-        bool want_jump = false, want_diag = false; int run = 0;
-        {
-            const int dd = nd & 7;
-            const int ddx = (dd == 0 || dd == 1 || dd == 7) ? 1 : ((dd >= 3 && dd <= 5) ? -1 : 0);
-            const int ddy = (dd >= 1 && dd <= 3) ? 1 : ((dd >= 5) ? -1 : 0);
-            const int rel = (s - nd) & 7;
-            const bool is_start = nd == 8, d_odd = (nd & 1) != 0 && !is_start, d_even = !d_odd && !is_start;
-            want_jump = nvalid && ((is_start && (s & 1) == 0) || (d_even && rel == 0) || (d_odd && (rel == 1 || rel == 7)));
-            const bool plain = nvalid && ((is_start && (s & 1) != 0) || (d_odd && rel == 0));
-            const bool sided = nvalid && ((d_even && (rel == 1 || rel == 7)) || (d_odd && (rel == 2 || rel == 6)));
-            const int px = d_odd ? (sdx - ddx) / 2 : sdx - ddx, py = d_odd ? (sdy - ddy) / 2 : sdy - ddy;
-            const bool t_free = (plain || sided) && !cell_blocked(Vrow, nx0 + sdx, ny0 + sdy);
-            const bool side_blk = sided && cell_blocked(Vrow, nx0 + px, ny0 + py);
-            want_diag = (plain && t_free) || (sided && side_blk && t_free);
-        }
+        const bool want_jump = nvalid && jump0, want_diag = nvalid && diag0;
+        int run = 0;
         DBG_MARK(2)
-        // ---- jumps.  Every straight scan is one lane (jump_lane).  A diagonal jump takes a group of kDiagGroup = 16
-        //      lanes: lane pair k = 0..6 scans horizontally | vertically from cell k+1 of the diagonal and its even lane
-        //      tests that cell (blocked / goal / forced); cell 8 only needs the test (whatever a scan found there, the
-        //      jump ends at that cell), so the last pair of every group is free for the straight successors of the
-        //      batch (<= 8; 4 for the start node).  Four diagonal jumps + all straight ones per round; a second round
-        //      only when a step has more than four diagonal successors.  The first cell with a finding ends a jump. ----
+        // ---- jumps.  The successor lanes post their jobs (x | y << 12 | s << 24) in LDS, diagonal ones in slots 0..15 and
+        //      straight ones in 16..23, in lane order; the scan lanes and the cell-test lanes pick them up. ----
         const unsigned smask = (unsigned)__ballot(want_jump), dmask = (unsigned)__ballot(want_diag);
         const int n_sj = __popc(smask), n_dc = __popc(dmask);
         const int my_sj = __popc(smask & ((1u << (lane & 31)) - 1u)), my_dc = __popc(dmask & ((1u << (lane & 31)) - 1u));
-        if (want_jump) {
-            const bool horiz = s == 0 || s == 4;
-            // view | sgn | line | pos, 12 bits each for line and pos (always inside the grid here)
-            L.sj_job[my_sj] = (horiz ? 0u : 1u) | ((s == 0 || s == 2) ? 2u : 0u) | ((uint32_t)(horiz ? ny0 : nx0) << 2) | ((uint32_t)(horiz ? nx0 : ny0) << 14);
-        }
-        if (want_diag) L.dc_owner[my_dc] = lane;
+        if (want_jump || want_diag) L.job[want_diag ? my_dc : kMaxDiag + my_sj] = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24);
         wave_order();
-        const int n_rounds_j = (n_sj | n_dc) ? max(1, (n_dc + kDiagPerRound - 1) / kDiagPerRound) : 0;
+        const int n_rounds_j = (n_sj | n_dc) ? max(1, (n_dc + 3) >> 2) : 0;
         for (int rnd = 0; rnd < n_rounds_j; rnd++) {
-            const int grp = lane / kDiagGroup, t = lane % kDiagGroup, kk = t >> 1;
-            const bool last = kk == kDiagK - 1;                                // the pair of cell 8 = the straight-jump lanes
-            const int dci = rnd * kDiagPerRound + grp;
-            const int sji = grp * 2 + (t & 1);
-            const bool dact = dci < n_dc, sact = rnd == 0 && last && sji < n_sj;
-            const int ol = L.dc_owner[dact ? dci : 0];
-            const int ox = __shfl(nx0, ol, 64), oy = __shfl(ny0, ol, 64);
-            const int os = ol & 7;
-            const int odx = (os == 1 || os == 7) ? 1 : -1, ody = (os == 1 || os == 3) ? 1 : -1;
-            const int cx = ox + (kk + 1) * odx, cy = oy + (kk + 1) * ody;
-            const uint32_t sj = L.sj_job[sact ? sji : 0];
-            bool hv = (t & 1) != 0;                                            // vertical scan?
-            int jl = hv ? cx : cy, jp = hv ? cy : cx, jsg = hv ? ody : odx;
-            if (last) { hv = (sj & 1u) != 0; jsg = (sj & 2u) ? 1 : -1; jl = (int)((sj >> 2) & 0xFFFu); jp = (int)(sj >> 14); }
-            const bool jact = last ? sact : dact;
+            // -- cell tests: lanes 0..31 = (job aj, cell ak) of this round --
+            const int dca = rnd * 4 + aj;
+            const bool a_act = lane < 32 && dca < n_dc;
+            const uint32_t Ja = L.job[a_act ? dca : 0];
+            // -- scans --
+            const int dcb = rnd * 4 + bj;
+            const bool b_act = is_dscan ? dcb < n_dc : (rnd == 0 && lane - 56 < n_sj);
+            const uint32_t Jb = L.job[b_act ? (is_dscan ? dcb : kMaxDiag + lane - 56) : 0];
+            int jl, jp, jsg; bool hv;
+            {
+                const int ox = (int)(Jb & 0xFFFu), oy = (int)((Jb >> 12) & 0xFFFu), os = (int)(Jb >> 24);
+                if (is_dscan) {
+                    const int odx = (os == 1 || os == 7) ? 1 : -1, ody = (os == 1 || os == 3) ? 1 : -1;
+                    const int cx = ox + bk * odx, cy = oy + bk * ody;
+                    hv = bhv; jl = hv ? cx : cy; jp = hv ? cy : cx; jsg = hv ? ody : odx;
+                } else {
+                    hv = !(os == 0 || os == 4); jsg = (os == 0 || os == 2) ? 1 : -1; jl = hv ? ox : oy; jp = hv ? oy : ox;
+                }
+            }
             const V vw = hv ? Vcol : Vrow;                                     // by value: per-lane field selects
-            // the scanned line and its two neighbours, described once: the scan and (horizontal lanes) the cell tests share them
-            const auto m0 = vw.line(jact || dact ? jl : -1), mP = vw.line(jact || dact ? jl + 1 : -1), mM = vw.line(jact || dact ? jl - 1 : -1);
-#ifdef DMPP_DEBUG_SEARCH
-            const int r = jump_lane(vw, m0, mP, mM, jact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx, &dbg_c[2]);
-#else
-            const int r = jump_lane(vw, m0, mP, mM, jact, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx);
-#endif
+            const auto m0 = vw.line(b_act ? jl : -1), mP = vw.line(b_act ? jl + 1 : -1), mM = vw.line(b_act ? jl - 1 : -1);
             bool cblk = false, cstop = false;
-            if (dact && (t & 1) == 0) {
-                // even lane of a pair: horizontal scan along row cy, so m0 / mP / mM are rows cy, cy + 1, cy - 1 of the row view
-                // (for the pair of cell 8 the lane scanned a straight job instead: its rows are looked up here)
-                const auto r0 = last ? Vrow.line(cy) : m0;
-                const auto ra = last ? Vrow.line(cy + ody) : (ody > 0 ? mP : mM);      // row cy + ody
-                const auto rb = last ? Vrow.line(cy - ody) : (ody > 0 ? mM : mP);      // row cy - ody
+            {
+                const int ox = (int)(Ja & 0xFFFu), oy = (int)((Ja >> 12) & 0xFFFu), os = (int)(Ja >> 24);
+                const int odx = (os == 1 || os == 7) ? 1 : -1, ody = (os == 1 || os == 3) ? 1 : -1;
+                const int cx = ox + ak * odx, cy = oy + ak * ody;
+                const auto r0 = Vrow.line(a_act ? cy : -1), ra = Vrow.line(a_act ? cy + ody : -1), rb = Vrow.line(a_act ? cy - ody : -1);
                 cblk = cell_blocked_m(Vrow, r0, cx);
                 const bool forced = (cell_blocked_m(Vrow, r0, cx - odx) && !cell_blocked_m(Vrow, ra, cx - odx)) ||
                                     (cell_blocked_m(Vrow, rb, cx) && !cell_blocked_m(Vrow, rb, cx + odx));
-                cstop = cblk || (cx == gx && cy == gy) || forced;
+                cstop = a_act && (cblk || (cx == gx && cy == gy) || forced);
+                cblk = cblk && a_act;
             }
-            const unsigned long long sm = __ballot(dact && (cstop || (!last && r > 0))), bk = __ballot(cblk);
-            const unsigned gs = (unsigned)(sm >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
-            const unsigned gb = (unsigned)(bk >> (grp * kDiagGroup)) & ((1u << kDiagGroup) - 1u);
-            int drun = kDiagK;
-            if (gs) { const int k1 = (__ffs((int)gs) - 1) >> 1; drun = ((gb >> (2 * k1)) & 1u) ? 0 : k1 + 1; }
-            // results back to the owner lanes: a straight one sits on lane 14 | 15 of group my_sj / 2, a diagonal one on its whole group
-            const int from_s = __shfl(r, ((my_sj >> 1) & (kDiagPerRound - 1)) * kDiagGroup + (kDiagGroup - 2) + (my_sj & 1), 64);
-            const int from_d = __shfl(drun, (my_dc & (kDiagPerRound - 1)) * kDiagGroup, 64);
+#ifdef DMPP_DEBUG_SEARCH
+            const int r = jump_lane(vw, m0, mP, mM, b_act, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx, &dbg_c[2]);
+#else
+            const int r = jump_lane(vw, m0, mP, mM, b_act, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx);
+#endif
+            // -- results.  Diagonal job j of the round: the first cell k with a cell-test stop (bits j*8 + k-1 of the test ballot)
+            //    or a scan hit (bits j*7 + k-1 of the horizontal / 28 + j*7 + k-1 of the vertical half of the scan ballot) ends
+            //    the jump; every owner lane works its own job out of the three wave-uniform masks. --
+            const unsigned long long am = __ballot(cstop), kb = __ballot(cblk), sb = __ballot(is_dscan && r > 0);
+            if (want_diag && (my_dc >> 2) == rnd) {
+                const int j = my_dc & 3;
+                const unsigned ta = (unsigned)(am >> (8 * j)) & 0xFFu, tk = (unsigned)(kb >> (8 * j)) & 0xFFu;
+                const unsigned sc = ((unsigned)(sb >> (7 * j)) | (unsigned)(sb >> (28 + 7 * j))) & 0x7Fu;
+                const unsigned any = ta | sc;
+                int drun = kDiagK;
+                if (any) { const int k1 = __ffs((int)any) - 1; drun = ((tk >> k1) & 1u) ? 0 : k1 + 1; }
+                run = drun;
+            }
+            const int from_s = __shfl(r, 56 + (my_sj & 7), 64);
             if (rnd == 0 && want_jump) run = from_s;
-            if (want_diag && (my_dc / kDiagPerRound) == rnd) run = from_d;
         }
         DBG_MARK(3)
 #ifdef DMPP_DEBUG_SEARCH
@@ -642,7 +725,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
         const unsigned pm = (unsigned)__ballot(push);
         const int cnt = __popc(pm);
         if (cnt) {
-            const int nx = nx0 + run * sdx, ny = ny0 + run * sdy;
+            const int nx = x + run * sdx, ny = y + run * sdy;
             const int fn = gcur + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
             // f/2 lives in 16 bits (0xFFFF = dead slot): a push at or beyond DMPP_F_LIMIT ends the search.  The oracle tests
             // each push in turn, the range before the capacity: the earlier of the two failing pushes decides the status.
@@ -653,25 +736,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
                 status = k_range <= k_cap ? DMPP_G_COST_RANGE : DMPP_G_OVERFLOW;
                 break;
             }
-            if (n_open + cnt > kOpenCap) {
-                // squeeze the dead slots out, keeping the push order (ballot + prefix popcount)
-                int w = 0;
-                for (int q0 = 0; q0 < n_open; q0 += DMPP_WAVE) {
-                    const int i = q0 + lane;
-                    uint32_t f2 = 0xFFFFu, ee = 0; uint16_t rr = 0;
-                    if (i < n_open) { f2 = L.o_f2[i]; ee = L.o_ent[i]; rr = L.o_run[i]; }
-                    const bool alive = f2 != 0xFFFFu;
-                    const unsigned long long am = __ballot(alive);
-                    wave_order();
-                    if (alive) {
-                        const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
-                        L.o_f2[w + r] = (uint16_t)f2; L.o_ent[w + r] = ee; L.o_run[w + r] = rr;
-                    }
-                    w += __popcll(am);
-                    wave_order();
-                }
-                n_open = w;
-            }
+            if (n_open + cnt > kOpenCap) n_open = squeeze_open(L, n_open, lane);      // keeps the push order
             if (push) {
                 const int slot = n_open + __popc(pm & ((1u << lane) - 1u));
                 L.o_f2[slot] = (uint16_t)(fn >> 1);
@@ -843,7 +908,8 @@ __device__ __forceinline__ void publish_debug(int32_t* path, int max_path, const
     dbg[0] = cn[0]; dbg[1] = cn[1]; dbg[2] = cn[2]; dbg[3] = cn[3]; dbg[4] = cn[4];
     dbg[5] = (int)(t[0] >> 4); dbg[6] = (int)(t[1] >> 4); dbg[7] = (int)(t[2] >> 4); dbg[8] = (int)(t[3] >> 4); dbg[9] = (int)(t[4] >> 4);
     dbg[10] = (int)(t[6] >> 4); dbg[11] = (int)((t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6]) >> 4); dbg[12] = (int)(t_setup >> 4); dbg[13] = (int)(t_total >> 4);
-    dbg[14] = 0; dbg[15] = 0;
+    dbg[14] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
+    dbg[15] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
 }
 #endif
 
@@ -862,7 +928,6 @@ k_search_lds(PlannerConfig c, int n_scenes, int order_cap, int budget, const int
     __shared__ SearchLds L;
     if ((int)blockIdx.x >= n_scenes) return;
     const long long t_begin = clock64();
-    __builtin_amdgcn_s_setprio(3);             // one latency-bound wave per scene: issue ahead of the kernels that run beside it
     const int scene = perm ? perm[blockIdx.x] : (int)blockIdx.x;      // heaviest scenes first (k_order) when they do not all fit at once
     const int tid = threadIdx.x, lane = tid & (DMPP_WAVE - 1), wv = tid >> 6;
     const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5, HW = H >> 5;
@@ -870,21 +935,30 @@ k_search_lds(PlannerConfig c, int n_scenes, int order_cap, int budget, const int
     // dynamic LDS layout
     SparseView<K> vr, vc;
     {
-        unsigned char* p = smem_raw;
+        DMPP_LDS unsigned char* p = (DMPP_LDS unsigned char*)smem_raw;
+        unsigned used = 0;
         if constexpr (K == 2) {
-            vr.meta = p; p += (size_t)H * 8; vc.meta = p; p += (size_t)W * 8;
-            vr.off2 = reinterpret_cast<uint32_t*>(p); p += (size_t)H * 4; vc.off2 = reinterpret_cast<uint32_t*>(p); p += (size_t)W * 4;
+            vr.meta = p; vc.meta = p + (unsigned)H * 8u;
+            vr.off2 = (DMPP_LDS uint32_t*)(p + (unsigned)(H + W) * 8u); vc.off2 = vr.off2 + H;
+            used = (unsigned)(H + W) * 12u;
         } else {
-            constexpr int mb = sparse_meta_bytes_per_line<K>();
-            vr.meta = p; p += (size_t)H * mb; vc.meta = p; p += (size_t)W * mb;
+            constexpr unsigned mb = (unsigned)sparse_meta_bytes_per_line<K>();
+            vr.meta = p; vc.meta = p + (unsigned)H * mb;
             vr.off2 = nullptr; vc.off2 = nullptr;
+            used = (unsigned)(H + W) * mb;
         }
-        p = reinterpret_cast<unsigned char*>(((uintptr_t)p + 15) & ~(uintptr_t)15);
-        vr.data = reinterpret_cast<uint32_t*>(p); vc.data = vr.data + budget;
+        used = (used + 15u) & ~15u;
+        vr.data = (DMPP_LDS uint32_t*)(p + used); vc.data = vr.data + budget;
         vr.LW = WW; vr.NL = H; vc.LW = HW; vc.NL = W;
     }
     for (int i = tid; i < kClosedTab; i += kSearchBlock) L.c_tab[i] = 0;
+    for (int i = tid; i < kOpenCap; i += kSearchBlock) L.o_f2[i] = 0xFFFFu;      // dead slots everywhere: the pop never range-checks
+#ifdef DMPP_DEBUG_SEARCH
+    long long tmark[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const int need = build_sparse_views<K>(c, si, obs_now + si.obs_off, si.obs_n, vr, vc, budget, L.s_wave, tmark);
+#else
     const int need = build_sparse_views<K>(c, si, obs_now + si.obs_off, si.obs_n, vr, vc, budget, L.s_wave);
+#endif
     if (tid == 0) { atomicMax(need_max, need); overflow[scene] = need > budget ? 1 : 0; }
     if (need > budget) return;                 // this scene goes to k_search_gbm (uniform over the block)
     const int start = cell_of(c, si.grid_origin, si.loc.globalpoint.x, si.loc.globalpoint.y);
@@ -899,6 +973,7 @@ k_search_lds(PlannerConfig c, int n_scenes, int order_cap, int budget, const int
     }
     __syncthreads();
     if (wv != 0) return;                       // set-up done: the search is wave 0's
+    __builtin_amdgcn_s_setprio(1);             // a latency-bound wave: ahead of the set-up waves and of the kernels that run beside it
     const long long t_setup = clock64() - t_begin;
     SearchOut R; R.status = DMPP_G_GOAL_BLOCKED; R.n_exp = 0; R.n_push = 0; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
     int32_t* path = paths + (size_t)scene * c.max_path;
@@ -913,7 +988,11 @@ k_search_lds(PlannerConfig c, int n_scenes, int order_cap, int budget, const int
 #endif
                         );
 #ifdef DMPP_DEBUG_SEARCH
-    if (lane == 0) publish_debug(path, c.max_path, dbg_t, dbg_c, t_setup, clock64() - t_begin);
+    if (lane == 0) {
+        publish_debug(path, c.max_path, dbg_t, dbg_c, t_setup, clock64() - t_begin);
+        int32_t* d2 = path + c.max_path - 32;      // set-up phases: entry->clear, footprints, pass 1, offsets, zero, pass 2, tail
+        d2[0] = (int)(tmark[0] - t_begin); for (int i = 1; i < 7; i++) d2[i] = (int)(tmark[i] - tmark[i - 1]); d2[7] = (int)(t_begin + t_setup - tmark[6]);
+    }
 #endif
     (void)t_setup;
     if (lane == 0) {
@@ -939,8 +1018,8 @@ k_search_gbm(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __rest
     const int tid = threadIdx.x, lane = tid & (DMPP_WAVE - 1), wv = tid >> 6;
     const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5, HW = H >> 5;
     const SceneIn& si = in[scene];
-    uint64_t* nz_row = reinterpret_cast<uint64_t*>(smem_raw);
-    uint64_t* nz_col = nz_row + H;
+    DMPP_LDS uint64_t* nz_row = (DMPP_LDS uint64_t*)smem_raw;
+    DMPP_LDS uint64_t* nz_col = nz_row + H;
     uint32_t* bm = gbitmaps + (size_t)scene * 2 * (N >> 5);
     uint32_t* bmT = bm + (N >> 5);
     const int start = cell_of(c, si.grid_origin, si.loc.globalpoint.x, si.loc.globalpoint.y);
@@ -957,7 +1036,7 @@ k_search_gbm(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __rest
         // line masks of both views (bit w = word w of the line is non-zero): one lane per line
         for (int v = 0; v < 2; v++) {
             const uint32_t* src = v ? bmT : bm;
-            uint64_t* nz = v ? nz_col : nz_row;
+            DMPP_LDS uint64_t* nz = v ? nz_col : nz_row;
             const int LW = v ? HW : WW, NL = v ? W : H;
             for (int line = tid; line < NL; line += kSearchBlock) {
                 uint64_t msk = 0;
@@ -966,6 +1045,8 @@ k_search_gbm(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __rest
             }
         }
         for (int i = tid; i < kClosedTab; i += kSearchBlock) L.c_tab[i] = 0;
+        for (int i = tid; i < kOpenCap; i += kSearchBlock) L.o_f2[i] = 0xFFFFu;
+        __syncthreads();
         if (tid == 0) {
             L.o_ent[0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
             L.o_f2[0] = (uint16_t)(hfun(start % W, start / W, goal % W, goal / W) >> 1);
@@ -1014,17 +1095,20 @@ k_export_grid(PlannerConfig c, int scene, int budget, const SceneIn* __restrict_
     const SceneIn& si = in[scene];
     SparseView<K> vr, vc;
     {
-        unsigned char* p = smem_raw;
+        DMPP_LDS unsigned char* p = (DMPP_LDS unsigned char*)smem_raw;
+        unsigned used = 0;
         if constexpr (K == 2) {
-            vr.meta = p; p += (size_t)H * 8; vc.meta = p; p += (size_t)W * 8;
-            vr.off2 = reinterpret_cast<uint32_t*>(p); p += (size_t)H * 4; vc.off2 = reinterpret_cast<uint32_t*>(p); p += (size_t)W * 4;
+            vr.meta = p; vc.meta = p + (unsigned)H * 8u;
+            vr.off2 = (DMPP_LDS uint32_t*)(p + (unsigned)(H + W) * 8u); vc.off2 = vr.off2 + H;
+            used = (unsigned)(H + W) * 12u;
         } else {
-            constexpr int mb = sparse_meta_bytes_per_line<K>();
-            vr.meta = p; p += (size_t)H * mb; vc.meta = p; p += (size_t)W * mb;
+            constexpr unsigned mb = (unsigned)sparse_meta_bytes_per_line<K>();
+            vr.meta = p; vc.meta = p + (unsigned)H * mb;
             vr.off2 = nullptr; vc.off2 = nullptr;
+            used = (unsigned)(H + W) * mb;
         }
-        p = reinterpret_cast<unsigned char*>(((uintptr_t)p + 15) & ~(uintptr_t)15);
-        vr.data = reinterpret_cast<uint32_t*>(p); vc.data = vr.data + budget;
+        used = (used + 15u) & ~15u;
+        vr.data = (DMPP_LDS uint32_t*)(p + used); vc.data = vr.data + budget;
         vr.LW = WW; vr.NL = H; vc.LW = HW; vc.NL = W;
     }
     const int need = build_sparse_views<K>(c, si, obs_now + si.obs_off, si.obs_n, vr, vc, budget, s_wave);

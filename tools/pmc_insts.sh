@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: dynamic instruction counts per kernel (rocprofv3 PMC, its own pass, kernel-trace only).
+#   gpurun -- 'bash tools/pmc_insts.sh <tag> [bench args]'
+set -e
+TAG=${1:-x}
+export TMPDIR=/tmp
+R=$PWD
+ARGS="--no-cpu-baseline --latency-ticks 0 ${@:2}"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $R/gpurun_out/pmc_${TAG} -- python3 bench.py --steps 3 --warmup 1 $ARGS > gpurun_out/pmc_${TAG}.log 2>&1
+python3 - <<PY
+import csv, glob, collections
+f = glob.glob("$R/gpurun_out/pmc_${TAG}/**/*counter_collection.csv", recursive=True)[0]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+seen = set()
+for r in csv.DictReader(open(f)):
+    k = r["Kernel_Name"].split("(")[0][:60]
+    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    key = (r["Dispatch_Id"]); 
+    if (k, key) not in seen: seen.add((k, key)); n[k] += 1
+for k in acc:
+    print(k, "dispatches", n[k], {c: round(v / n[k]) for c, v in acc[k].items()})
+PY

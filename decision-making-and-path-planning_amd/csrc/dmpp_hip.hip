@@ -32,6 +32,10 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct EvPair { hipEvent_t a, b; int k; };
 
+// Buffers that a tick's search and scoring touch exist kBuf times, used round-robin ("parity"): up to kBuf searches of
+// consecutive ticks are in flight at once, each on its own stream, and scoring of tick t never holds up the search of t + 1.
+constexpr int kBuf = 3;
+
 }  // namespace
 
 struct pp_planner {
@@ -42,33 +46,33 @@ struct pp_planner {
     hipStream_t stream = nullptr;
     // inputs
     SceneIn* d_in = nullptr; GlobalPoint3D* d_lane = nullptr; uint8_t* d_attr = nullptr; bool have_attr = false; GlobalPoint2D* d_ref = nullptr;
-    ObPoint* d_obs = nullptr; ObMotion* d_mot = nullptr; ObPoint* d_obs_now[2] = { nullptr, nullptr };
+    ObPoint* d_obs = nullptr; ObMotion* d_mot = nullptr; ObPoint* d_obs_now[kBuf] = {};
     bool have_motion = false;
     // state / outputs
-    SceneState* d_state = nullptr; PlanOut* d_plan = nullptr; GridOut* d_gout[2] = { nullptr, nullptr };
+    SceneState* d_state = nullptr; PlanOut* d_plan = nullptr; GridOut* d_gout[kBuf] = {};
     GlobalPoint2D* d_dec_ref = nullptr;
     // grid engine
-    uint8_t* d_grid = nullptr; uint16_t* d_pinfo[2] = { nullptr, nullptr }; uint32_t* d_closed[2] = { nullptr, nullptr };
-    int32_t* d_order[2] = { nullptr, nullptr }; int32_t* d_path[2] = { nullptr, nullptr }; uint32_t* d_gbm[2] = { nullptr, nullptr };
-    int32_t* d_perm[2] = { nullptr, nullptr }; int32_t* d_cost[2] = { nullptr, nullptr };
+    uint8_t* d_grid = nullptr; uint16_t* d_pinfo[kBuf] = {}; uint32_t* d_closed[kBuf] = {};
+    int32_t* d_order[kBuf] = {}; int32_t* d_path[kBuf] = {}; uint32_t* d_gbm[kBuf] = {};
+    int32_t* d_perm[kBuf] = {}; int32_t* d_cost[kBuf] = {};
     // Long searches (many obstacles, large grids) overlap their tails: the searches of odd ticks run on a second stream, and
     // every buffer a search touches exists per tick parity
-    hipStream_t stream_m2 = nullptr; int n_obs_total = 0; int overlap_override = -1;
+    hipStream_t stream_m[kBuf] = {}; int n_obs_total = 0; int overlap_override = -1;     // stream_m[0] is the handle's stream int overlap_override = -1;
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
     // search: k_search_lds<kind> with `lds_budget` data words per view in LDS; scenes that need more go to k_search_gbm
     int search_kind = 0; int search_meta_bytes = 0; int lds_budget = 0, lds_budget_max = 0; bool lds_budget_fixed = false, search_force_gbm = false;
     int gbm_lds = 0; int search_slots = 512;
-    int32_t* d_ovf[2] = { nullptr, nullptr }; int32_t* d_need[2] = { nullptr, nullptr }; int32_t* h_need = nullptr;   // h_need: pinned, [2]
-    hipEvent_t ev_need[2] = { nullptr, nullptr }; bool need_pending[2] = { false, false }; int need_seen = 0;
+    int32_t* d_ovf[kBuf] = {}; int32_t* d_need[kBuf] = {}; int32_t* h_need = nullptr;   // h_need: pinned, [kBuf]
+    hipEvent_t ev_need[kBuf] = {}; bool need_pending[kBuf] = {}; int need_seen = 0;
     int* d_gridbad = nullptr;
     int raster_band_rows = 0; bool raster_band_fixed = false;
     hipStream_t stream_r = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the R kernels run beside the grid engine
     // k_score of tick t runs on its own stream beside the rasterise / search of tick t+1: the obstacle snapshot, the path
     // cells and GridOut are double-buffered by tick parity; ev_score[p] = the last k_score that used the buffers p
-    hipStream_t stream_s = nullptr; hipEvent_t ev_search[2] = { nullptr, nullptr }, ev_score[2] = { nullptr, nullptr };
+    hipStream_t stream_s = nullptr; hipEvent_t ev_search[kBuf] = {}, ev_score[kBuf] = {};
     hipEvent_t ev_raster = nullptr;
-    bool score_recorded[2] = { false, false }, search_recorded[2] = { false, false }, front_recorded = false, front_unjoined = false;
+    bool score_recorded[kBuf] = {}, search_recorded[kBuf] = {}, front_recorded = false, front_unjoined = false;
     int parity = 0;              // buffers of the last tick
     int n_cus = 256;
     int pipeline_min = 256;      // batches at least this large run the three chains on three streams (env DMPP_PIPELINE_MIN)
@@ -125,7 +129,7 @@ constexpr int kScoreWideMaxScenes = 128;     // up to here k_score runs 16 waves
 // Decision -> Planning chain (stream order covers the earlier ticks).  No host wait.
 int join_all(pp_planner* h)
 {
-    for (int q = 0; q < 2; q++) if (h->score_recorded[q]) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_score[q], 0));
+    for (int q = 0; q < kBuf; q++) if (h->score_recorded[q]) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_score[q], 0));
     if (h->front_recorded) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     return PP_OK;
 }
@@ -220,7 +224,7 @@ int setup_grid_launch(pp_planner* h)
     if (const char* e = std::getenv("DMPP_LDS_BUDGET")) {                                                // ... a fixed budget (words per view)
         h->lds_budget = std::max(1, std::min(std::atoi(e), h->lds_budget_max)); h->lds_budget_fixed = true;
     } else h->lds_budget = 0;                                                                            // chosen at the first tick (obstacle density), then adaptive
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < kBuf; q++) {
         if (!h->d_ovf[q]) {
             int r = dmalloc(&h->d_ovf[q], (size_t)h->caps.max_scenes); if (r) return r;
             HIP_TRY(hipMemsetAsync(h->d_ovf[q], 0, (size_t)h->caps.max_scenes * sizeof(int32_t), h->stream));
@@ -228,18 +232,18 @@ int setup_grid_launch(pp_planner* h)
         if (!h->d_need[q]) { int r = dmalloc(&h->d_need[q], (size_t)1); if (r) return r; }
         if (!h->ev_need[q]) HIP_TRY(hipEventCreateWithFlags(&h->ev_need[q], hipEventDisableTiming));
     }
-    if (!h->h_need) { HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_need), 2 * sizeof(int32_t), hipHostMallocDefault)); h->h_need[0] = h->h_need[1] = 0; }
+    if (!h->h_need) { HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_need), kBuf * sizeof(int32_t), hipHostMallocDefault)); for (int q = 0; q < kBuf; q++) h->h_need[q] = 0; }
     if (!h->d_gridbad) { int r = dmalloc(&h->d_gridbad, (size_t)2); if (r) return r; }
     if (sizeof(dmpp::ScoreShared<16>) > 48u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_score<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(dmpp::ScoreShared<16>));
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < kBuf; q++) {
         if (!h->d_perm[q]) { int r = dmalloc(&h->d_perm[q], (size_t)h->caps.max_scenes); if (r) return r; }
         if (!h->d_cost[q]) {
             int r = dmalloc(&h->d_cost[q], (size_t)h->caps.max_scenes); if (r) return r;
             HIP_TRY(hipMemsetAsync(h->d_cost[q], 0, (size_t)h->caps.max_scenes * sizeof(int32_t), h->stream));
         }
     }
-    for (int q = 0; q < 2; q++) if (!h->d_gbm[q]) {   // bit-packed occupancy, row- and column-major: written by k_rasterise, read by k_search
+    for (int q = 0; q < kBuf; q++) if (!h->d_gbm[q]) {   // bit-packed occupancy, row- and column-major: written by k_rasterise, read by k_search
         int r = dmalloc(&h->d_gbm[q], (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
         if (r) return r;
     }
@@ -273,7 +277,9 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
-    if (hipStreamCreateWithPriority(&h->stream_m2, hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    h->stream_m[0] = h->stream;
+    for (int q = 1; q < kBuf; q++)
+        if (hipStreamCreateWithPriority(&h->stream_m[q], hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     // The two side streams (front, score) may use 88 % of the CUs; the rest run nothing but search waves.  The search
     // needs two 80 KB workgroups per CU and the hardware does not keep the short kernels' workgroups out of its way by
     // queue priority alone; measured on configs[1] (with the time-keyed launch order): 0.596 ms per tick without the
@@ -297,11 +303,10 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     if (hipStreamCreateWithPriority(&h->stream_s, hipStreamNonBlocking, prio_least) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_search[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_search[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_raster, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_score[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_score[1], hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
+        hipEventCreateWithFlags(&h->ev_raster, hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
+    for (int q = 0; q < kBuf; q++)
+        if (hipEventCreateWithFlags(&h->ev_search[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_score[q], hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
     const size_t ns = (size_t)caps->max_scenes;
     if ((r = dmalloc(&h->d_in, ns))) return bail(r);
     if ((r = dmalloc(&h->d_lane, (size_t)caps->max_lane_pts_total))) return bail(r);
@@ -312,23 +317,23 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     if (hipMemsetAsync(h->d_mot, 0, (size_t)(caps->max_obs_total > 0 ? caps->max_obs_total : 1) * sizeof(ObMotion), h->stream) != hipSuccess)
         return bail(fail(PP_ERR_HIP, "memset failed"));     // velocities nobody uploaded are zero, never uninitialised
     if ((r = dmalloc(&h->d_bad, (size_t)1))) return bail(r);
-    for (int q = 0; q < 2; q++) if ((r = dmalloc(&h->d_obs_now[q], (size_t)caps->max_obs_total))) return bail(r);
+    for (int q = 0; q < kBuf; q++) if ((r = dmalloc(&h->d_obs_now[q], (size_t)caps->max_obs_total))) return bail(r);
     if ((r = dmalloc(&h->d_state, ns))) return bail(r);
     if ((r = dmalloc(&h->d_plan, ns))) return bail(r);
-    for (int q = 0; q < 2; q++) if ((r = dmalloc(&h->d_gout[q], ns))) return bail(r);
+    for (int q = 0; q < kBuf; q++) if ((r = dmalloc(&h->d_gout[q], ns))) return bail(r);
     if ((r = dmalloc(&h->d_dec_ref, ns * DMPP_MAX_REFPATH))) return bail(r);
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < kBuf; q++)
         if (hipMemsetAsync(h->d_gout[q], 0, ns * sizeof(GridOut), h->stream) != hipSuccess) return bail(fail(PP_ERR_HIP, "memset failed"));
     if (cfg->grid_stage) {
         h->grid_cells = (size_t)cfg->grid_w * cfg->grid_h;
         h->bucket_cap0 = cfg->bucket_cap; h->max_path0 = cfg->max_path;
         if ((r = dmalloc(&h->d_grid, h->grid_cells))) return bail(r);             // one scene as bytes, filled on demand (pp_get_grid)
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < kBuf; q++) {
             if ((r = dmalloc(&h->d_pinfo[q], ns * h->grid_cells))) return bail(r);
             if ((r = dmalloc(&h->d_closed[q], ns * (h->grid_cells / 32)))) return bail(r);
         }
-        for (int q = 0; q < 2; q++) if ((r = dmalloc(&h->d_path[q], ns * (size_t)cfg->max_path))) return bail(r);
-        for (int q = 0; q < 2; q++) if (caps->order_cap > 0 && (r = dmalloc(&h->d_order[q], ns * (size_t)caps->order_cap))) return bail(r);
+        for (int q = 0; q < kBuf; q++) if ((r = dmalloc(&h->d_path[q], ns * (size_t)cfg->max_path))) return bail(r);
+        for (int q = 0; q < kBuf; q++) if (caps->order_cap > 0 && (r = dmalloc(&h->d_order[q], ns * (size_t)caps->order_cap))) return bail(r);
         if ((r = setup_grid_launch(h))) return bail(r);
     }
     h->scratch_bytes = 4u << 20;
@@ -342,25 +347,28 @@ int pp_destroy(pp_handle h)
 {
     if (!h) return PP_OK;
     (void)hipSetDevice(h->device);
-    for (hipStream_t st : { h->stream, h->stream_m2, h->stream_r, h->stream_s }) if (st) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : { h->stream, h->stream_r, h->stream_s }) if (st) (void)hipStreamSynchronize(st);
+    for (int q = 1; q < kBuf; q++) if (h->stream_m[q]) (void)hipStreamSynchronize(h->stream_m[q]);
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     if (h->stream_s) (void)hipStreamSynchronize(h->stream_s);
-    void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_obs_now[0], h->d_obs_now[1], h->d_state, h->d_plan,
-                     h->d_gout[0], h->d_gout[1], h->d_dec_ref, h->d_grid, h->d_pinfo[0], h->d_pinfo[1], h->d_closed[0], h->d_closed[1],
-                     h->d_order[0], h->d_order[1], h->d_path[0], h->d_path[1], h->d_gbm[0], h->d_gbm[1], h->d_perm[0], h->d_perm[1],
-                     h->d_cost[0], h->d_cost[1], h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad, h->d_bad,
-                     h->d_ovf[0], h->d_ovf[1], h->d_need[0], h->d_need[1], h->d_gridbad };
+    void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_state, h->d_plan,
+                     h->d_dec_ref, h->d_grid, h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad, h->d_bad,
+                     h->d_gridbad };
     for (void* b : bufs) if (b) (void)hipFree(b);
-    for (int q = 0; q < 2; q++) { if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]); if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]); }
+    for (int q = 0; q < kBuf; q++)
+        for (void* b : { (void*)h->d_obs_now[q], (void*)h->d_gout[q], (void*)h->d_pinfo[q], (void*)h->d_closed[q], (void*)h->d_order[q], (void*)h->d_path[q],
+                         (void*)h->d_gbm[q], (void*)h->d_perm[q], (void*)h->d_cost[q], (void*)h->d_ovf[q], (void*)h->d_need[q] })
+            if (b) (void)hipFree(b);
+    for (int q = 0; q < kBuf; q++) { if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]); if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]); }
     if (h->ev_raster) (void)hipEventDestroy(h->ev_raster);
-    for (int q = 0; q < 2; q++) if (h->ev_need[q]) (void)hipEventDestroy(h->ev_need[q]);
+    for (int q = 0; q < kBuf; q++) if (h->ev_need[q]) (void)hipEventDestroy(h->ev_need[q]);
     if (h->h_need) (void)hipHostFree(h->h_need);
     if (h->stream_s) (void)hipStreamDestroy(h->stream_s);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream_r) { (void)hipStreamSynchronize(h->stream_r); (void)hipStreamDestroy(h->stream_r); }
-    if (h->stream_m2) (void)hipStreamDestroy(h->stream_m2);
+    for (int q = 1; q < kBuf; q++) if (h->stream_m[q]) (void)hipStreamDestroy(h->stream_m[q]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PP_OK;
@@ -558,14 +566,14 @@ int pp_plan_tick(pp_handle h)
     //   search(t) waits for the snapshot of front(t) and for score(t-2) [path / GridOut p];  score(t) waits for search(t).
     // Small batches and ticks without the grid stage stay on one stream (a cross-stream hand-over costs tens of
     // microseconds; only Decision + Planning run beside the grid engine there).
-    const int p = h->parity ^ 1;
+    const int p = (h->parity + 1) % kBuf, p_prev = h->parity;
     const bool piped = c.grid_stage && n >= h->pipeline_min;
     if (c.grid_stage && !h->search_force_gbm) {
         // LDS budget of the search (data words per view).  First tick: from the obstacle density; afterwards from what the
         // densest scene of an earlier tick needed (+ 1/8), read from pinned memory once its copy has landed - never waited for.
         if (!h->lds_budget_fixed) {
             int need = -1;
-            for (int q = 0; q < 2; q++)
+            for (int q = 0; q < kBuf; q++)
                 if (h->need_pending[q] && hipEventQuery(h->ev_need[q]) == hipSuccess) { h->need_pending[q] = false; need = std::max(need, (int)h->h_need[q]); }
             (void)hipGetLastError();               // hipEventQuery's "not ready" is not an error
             int want = h->lds_budget;
@@ -587,18 +595,18 @@ int pp_plan_tick(pp_handle h)
         const size_t per_wg = sizeof(dmpp::SearchLds) + 64 + (size_t)h->gbm_lds;
         h->search_slots = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / per_wg)) * std::max(1, h->n_cus);
     }
-    // consecutive searches overlap when a search is long next to the front chain (Decision, Planning and the rasteriser share
-    // one stream and bound the tick from below): many obstacles per scene, or grids beyond 512 x 512.  Measured: 256 obstacles
-    // +40 %, 2048 x 2048 +7 %, but -8 % on 64 obstacles at 512 x 512, where the front chain is as long as the search.
-    bool overlap = piped && ((long long)c.grid_w * c.grid_h > 512ll * 512ll || (long long)h->n_obs_total >= 128ll * n);
+    // Consecutive searches overlap: a search ends with a handful of long scenes and would leave most of the chip idle; the searches
+    // of up to kBuf consecutive ticks run on their own streams (every buffer a search or a scoring pass touches exists kBuf times).
+    bool overlap = piped;
     if (h->overlap_override >= 0) overlap = piped && h->overlap_override != 0;      // env DMPP_OVERLAP (measurement knob)
-    hipStream_t sm = (overlap && p) ? h->stream_m2 : h->stream;        // search chain
+    hipStream_t sm = overlap ? h->stream_m[p] : h->stream;             // search chain
     hipStream_t sf = piped ? h->stream_r : h->stream;                  // front chain
     hipStream_t ss = piped ? h->stream_s : h->stream;                  // score chain
     hipStream_t sr = c.grid_stage ? h->stream_r : h->stream;           // Decision + Planning
     if (h->score_recorded[p]) { HIP_TRY(hipStreamWaitEvent(sf, h->ev_score[p], 0)); HIP_TRY(hipStreamWaitEvent(sm, h->ev_score[p], 0)); }
     if (h->search_recorded[p]) HIP_TRY(hipStreamWaitEvent(sf, h->ev_search[p], 0));
-    if (!overlap && h->search_recorded[p ^ 1]) HIP_TRY(hipStreamWaitEvent(sm, h->ev_search[p ^ 1], 0));   // one search at a time (also after a switch of mode)
+    if (!overlap)                                                      // one search at a time (also after a switch of mode)
+        for (int q = 0; q < kBuf; q++) if (q != p && h->search_recorded[q]) HIP_TRY(hipStreamWaitEvent(sm, h->ev_search[q], 0));
     if (h->front_recorded && sf == h->stream && h->front_unjoined) HIP_TRY(hipStreamWaitEvent(sf, h->ev_join, 0));   // Planning(t-1) -> snapshot(t) when not on the same stream
     h->front_unjoined = false;
     if (h->r_on_main && sf != h->stream) {         // Planning(t-1) ran on the handle's stream (grid stage off then): the front chain reads its state
@@ -634,7 +642,7 @@ int pp_plan_tick(pp_handle h)
         if (sf != sm) HIP_TRY(hipStreamWaitEvent(sm, h->ev_raster, 0));
         const int32_t* perm = order_scenes ? h->d_perm[p] : nullptr;
         if (perm && !order_in_front)          // one-stream tick with more scenes than search slots (DMPP_PIPELINE_MIN raised): keyed by the previous tick
-            hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[p ^ 1], h->d_perm[p]);
+            hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[p_prev], h->d_perm[p]);
         const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
         const size_t raster_lds = 2 * ((size_t)h->raster_band_rows * c.grid_w / 8);
         if (h->search_force_gbm) {            // measurement / test knob: every scene on dense bitmaps in HBM

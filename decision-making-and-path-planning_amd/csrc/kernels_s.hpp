@@ -689,11 +689,12 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
                 const int odx = (os == 1 || os == 7) ? 1 : -1, ody = (os == 1 || os == 3) ? 1 : -1;
                 const int cx = ox + ak * odx, cy = oy + ak * ody;
                 const auto r0 = Vrow.line(a_act ? cy : -1), ra = Vrow.line(a_act ? cy + ody : -1), rb = Vrow.line(a_act ? cy - ody : -1);
-                cblk = cell_blocked_m(Vrow, r0, cx);
-                const bool forced = (cell_blocked_m(Vrow, r0, cx - odx) && !cell_blocked_m(Vrow, ra, cx - odx)) ||
-                                    (cell_blocked_m(Vrow, rb, cx) && !cell_blocked_m(Vrow, rb, cx + odx));
-                cstop = a_act && (cblk || (cx == gx && cy == gy) || forced);
-                cblk = cblk && a_act;
+                // five independent reads, combined without short-circuits: one wait for all of them, no branches
+                const bool b0 = cell_blocked_m(Vrow, r0, cx), b1 = cell_blocked_m(Vrow, r0, cx - odx), b2 = cell_blocked_m(Vrow, ra, cx - odx);
+                const bool b3 = cell_blocked_m(Vrow, rb, cx), b4 = cell_blocked_m(Vrow, rb, cx + odx);
+                const bool forced = (b1 & !b2) | (b3 & !b4);
+                cstop = a_act & (b0 | ((cx == gx) & (cy == gy)) | forced);
+                cblk = b0 & a_act;
             }
 #ifdef DMPP_DEBUG_SEARCH
             const int r = jump_lane(vw, m0, mP, mM, b_act, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx, &dbg_c[2]);

@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-GRID_KERNELS = ("k_effective_obstacles", "k_rasterise", "k_order", "k_search", "k_search_fallback", "k_score")
+GRID_KERNELS = ("k_effective_obstacles", "k_order", "k_search", "k_score")
 
 
 def parse():
@@ -48,6 +48,7 @@ def parse():
                     help="gloo: rehearsal of the N > 1 path with ranks sharing the GPUs of a smaller box (never a measured number)")
     ap.add_argument("--dump-gathered", default=None, help="rank 0 writes the gathered PlanOut / SceneState / GridOut of all ranks to this .npz (tests)")
     ap.add_argument("--no-verify-gather", action="store_true", help="skip the bit-for-bit check of the gathered shards on rank 0")
+    ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the kernels of the timed region (no per-kernel times, no roofline)")
     return ap.parse_args()
 
 
@@ -93,10 +94,9 @@ def algorithmic_bytes(cfg, n_obs):
         "k_decision": 480 * 24 + 24 * n_obs + 6 * 48 + 120 * 16,
         "k_planning": b_r,
         "k_front": 480 * 24 + 24 * n_obs + 6 * 48 + 120 * 16 + b_r,   # Decision + Planning in one launch
-        "k_rasterise": W * H + 24 * n_obs,           # one write per cell (the device writes it bit-packed, twice: W*H/4 bytes)
-        "k_search": W * H + 3200,                    # one read per cell + the path out (read bit-packed: W*H/4 bytes)
+        "k_search": W * H + 24 * n_obs + 3200,       # SURVEY 8(d) B_G: one byte per grid cell + the obstacle list in + the path out (the kernel
+                                                     # rasterises into LDS and never moves the grid through HBM: see roofline.traffic)
         "k_score": 24 * n_obs + 3200 + 3200,
-        "k_search_fallback": W * H + 3200,
     }
     return b_r, b_g, per_kernel
 
@@ -170,7 +170,7 @@ def main():
     for _ in range(args.warmup):
         pl.tick()
     barrier()
-    pl.set_profile(True)
+    pl.set_profile(not args.no_kernel_events)
     pl.reset_kernel_ms()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -265,12 +265,12 @@ def main():
         r_dt = time.perf_counter() - r0
         pl.set_config(cfg)
         g_ms = sum(v[0] / max(v[1], 1) for k, v in kms.items() if k in GRID_KERNELS)
-        front_ms = sum(v[0] / max(v[1], 1) for k, v in kms.items() if k in ("k_effective_obstacles", "k_rasterise", "k_decision", "k_planning", "k_front"))
+        front_ms = sum(v[0] / max(v[1], 1) for k, v in kms.items() if k in ("k_effective_obstacles", "k_decision", "k_planning", "k_front"))
         parts = {"R_only_ticks_per_s": n * args.steps / r_dt, "R_only_ms_per_step": r_dt / args.steps * 1e3,
                  "G_kernels_serial_ms": g_ms, "G_kernels_serial_ticks_per_s": (n / (g_ms * 1e-3)) if g_ms > 0 else None,
                  "front_chain_ms": front_ms,
                  "note": "per GPU; R = Decision + Planning with the grid stage off; G = sum of the grid-engine kernels' average launch times "
-                         "inside the combined tick; front_chain = obstacle snapshot + rasterise + Decision + Planning, the kernels that share one stream beside the search"}
+                         "inside the combined tick; front_chain = obstacle snapshot + Decision + Planning, the kernels that share one stream beside the searches"}
 
     # ---- p50 plan latency, batch = 1 (rank 0): the C-ABI tick, and the C++ class surface CDecision::decide -> CPlanning::plan ----
     p50_ms = None

@@ -20,7 +20,7 @@ GEN_LANE_PTS, GEN_REF_PTS = 320, 128
 
 G_FOUND, G_NO_PATH, G_LIMIT, G_OVERFLOW, G_GOAL_BLOCKED, G_PATH_TRUNC, G_INTERNAL, G_COST_RANGE = range(8)
 G_STATUS_COUNT = 8
-K_NAMES = ["k_effective_obstacles", "k_decision", "k_planning", "k_rasterise", "k_search", "k_score", "k_search_fallback"]
+K_NAMES = ["k_effective_obstacles", "k_decision", "k_planning", "k_search", "k_score"]
 (BUF_SCENE_IN, BUF_LANE_POOL, BUF_REF_POOL, BUF_OBS_POOL, BUF_MOT_POOL, BUF_STATE, BUF_PLAN_OUT, BUF_GRID_OUT,
  BUF_GRID, BUF_PATH, BUF_ORDER, BUF_LANE_ATTR) = range(12)
 
@@ -132,6 +132,7 @@ def load_library(path=None):
     lib.pp_set_scenes.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, vp, ci]
     lib.pp_set_n_scenes.argtypes = [vp, ci, ci, ci, ci, ci, ci]
     lib.pp_join.argtypes = [vp]
+    lib.pp_get_search_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     lib.pp_set_map.argtypes = [vp, vp]
     lib.pp_set_egos.argtypes = [vp, ci, vp, vp, vp, ci]
     lib.pp_get_scene_in.argtypes = [vp, vp, ci]
@@ -305,6 +306,12 @@ class Planner:
         out = np.zeros((hgt, w), np.uint8)
         _check(self.lib.pp_get_grid(self.h, scene, _ptr(out)))
         return out
+
+    def search_info(self):
+        """(LDS budget in words per view, words the densest scene needed, scenes of the last tick on the dense path)."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _check(self.lib.pp_get_search_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def get_order(self, scene, n):
         out = np.zeros(max(n, 1), np.int32)

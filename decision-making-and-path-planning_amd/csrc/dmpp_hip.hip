@@ -66,7 +66,7 @@ struct pp_planner {
     int32_t* d_ovf[kBuf] = {}; int32_t* d_need[kBuf] = {}; int32_t* h_need = nullptr;   // h_need: pinned, [kBuf]
     hipEvent_t ev_need[kBuf] = {}; bool need_pending[kBuf] = {}; int need_seen = 0;
     int* d_gridbad = nullptr;
-    int raster_band_rows = 0; bool raster_band_fixed = false;
+
     hipStream_t stream_r = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the R kernels run beside the grid engine
     // k_score of tick t runs on its own stream beside the rasterise / search of tick t+1: the obstacle snapshot, the path
     // cells and GridOut are double-buffered by tick parity; ev_score[p] = the last k_score that used the buffers p
@@ -158,34 +158,11 @@ int drain_events(pp_planner* h)
     return PP_OK;
 }
 
-// Rows per band of k_rasterise.  128 whole rows is the measured optimum for batches that fill the chip (16-byte pieces
-// of the column-major bitmap per column and band); a handful of scenes gets narrower bands - halved while the result
-// stays a multiple of 32 rows - until there are some 512 workgroups (one scene at 512 x 512: 16 us -> 10 us).
-int raster_band_rows_for(int grid_h, int n_scenes, int base)
-{
-    int band = base < 32 ? 32 : base / 32 * 32;
-    if (band > grid_h) band = grid_h;
-    while (band % 64 == 0 && (long long)n_scenes * ((grid_h + band - 1) / band) < 512) band /= 2;
-    return band;
-}
-
 int setup_grid_launch(pp_planner* h)
 {
     const PlannerConfig& c = h->cfg;
     if (!c.grid_stage) return PP_OK;
     const size_t N = (size_t)c.grid_w * c.grid_h;
-    // rasterise: bands of <= 65536 cells (8 KiB of LDS bits), whole rows
-    // rasterise: bands of 128 whole rows (measured best at 512 and at 2048 columns: 16-byte pieces of the column-major
-    // bitmap per column and band, 4 - 16 bands per scene), both orientations of a band in LDS (32 bytes per column)
-    int band = 128;
-    if (const char* e = std::getenv("DMPP_RASTER_BAND_ROWS")) { band = std::atoi(e) / 32 * 32; h->raster_band_fixed = true; }   // tuning knob
-    if (band < 32) band = 32; if (band > c.grid_h) band = c.grid_h;
-    h->raster_band_rows = band;
-    {   // both LDS bit bands of k_rasterise (row- and column-major) + its 10 KB of static tables
-        const size_t lds = 2 * ((size_t)band * c.grid_w / 8);
-        if (lds + 12288 > 48u * 1024u)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_rasterise), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
     // search: per-line metas of both sparse views + the budgeted data words in dynamic LDS (kernels_s.hpp)
     const int lw = (int)std::max((size_t)c.grid_w / 32, (size_t)c.grid_h / 32);
     h->search_kind = lw <= 16 ? 0 : (lw <= 32 ? 1 : 2);
@@ -199,17 +176,17 @@ int setup_grid_launch(pp_planner* h)
     }
     if (lds_max > 160u * 1024u) lds_max = 160u * 1024u;
     h->gbm_lds = (int)(((size_t)c.grid_w + c.grid_h) * 8);
-    if ((size_t)h->search_meta_bytes + static_lds + 2 * 64 * 4 > lds_max || (size_t)h->gbm_lds + static_lds > lds_max)
+    if (std::max((size_t)h->search_meta_bytes + 2 * 64 * 4, (size_t)h->gbm_lds) + static_lds > lds_max)
         return fail(PP_ERR_CAPACITY, "grid too large for the search kernel's LDS tables");
     {
         const size_t room = (lds_max - static_lds - (size_t)h->search_meta_bytes) / 8;        // data words per view that fit at all
         const size_t dense = N / 32;                                                            // ... that a view can ever need
         h->lds_budget_max = (int)std::min(room, dense);
-        const void* fns[3] = { reinterpret_cast<const void*>(&dmpp::k_search_lds<0>), reinterpret_cast<const void*>(&dmpp::k_search_lds<1>),
-                               reinterpret_cast<const void*>(&dmpp::k_search_lds<2>) };
+        const void* fns[3] = { reinterpret_cast<const void*>(&dmpp::k_search<0>), reinterpret_cast<const void*>(&dmpp::k_search<1>),
+                               reinterpret_cast<const void*>(&dmpp::k_search<2>) };
         const void* fne[3] = { reinterpret_cast<const void*>(&dmpp::k_export_grid<0>), reinterpret_cast<const void*>(&dmpp::k_export_grid<1>),
                                reinterpret_cast<const void*>(&dmpp::k_export_grid<2>) };
-        const int dyn_max = h->search_meta_bytes + 8 * h->lds_budget_max;
+        const int dyn_max = std::max(h->search_meta_bytes + 8 * h->lds_budget_max, h->gbm_lds);
         if (dyn_max + (int)static_lds > 48 * 1024) {
             if (hipFuncSetAttribute(fns[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess ||
                 hipFuncSetAttribute(fne[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess) {
@@ -217,10 +194,8 @@ int setup_grid_launch(pp_planner* h)
                 h->lds_budget_max = (int)std::min((size_t)h->lds_budget_max, (48u * 1024u - static_lds - (size_t)h->search_meta_bytes) / 8);
             }
         }
-        if ((size_t)h->gbm_lds + static_lds > 48u * 1024u)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_search_gbm), hipFuncAttributeMaxDynamicSharedMemorySize, h->gbm_lds));
     }
-    if (const char* e = std::getenv("DMPP_SEARCH_GBM")) h->search_force_gbm = std::atoi(e) != 0;          // test / measurement knob: dense bitmaps in HBM for every scene
+    if (const char* e = std::getenv("DMPP_SEARCH_GBM")) h->search_force_gbm = std::atoi(e) != 0;          // test / measurement knob: the dense form in HBM for every scene
     if (const char* e = std::getenv("DMPP_LDS_BUDGET")) {                                                // ... a fixed budget (words per view)
         h->lds_budget = std::max(1, std::min(std::atoi(e), h->lds_budget_max)); h->lds_budget_fixed = true;
     } else h->lds_budget = 0;                                                                            // chosen at the first tick (obstacle density), then adaptive
@@ -243,7 +218,7 @@ int setup_grid_launch(pp_planner* h)
             HIP_TRY(hipMemsetAsync(h->d_cost[q], 0, (size_t)h->caps.max_scenes * sizeof(int32_t), h->stream));
         }
     }
-    for (int q = 0; q < kBuf; q++) if (!h->d_gbm[q]) {   // bit-packed occupancy, row- and column-major: written by k_rasterise, read by k_search
+    for (int q = 0; q < kBuf; q++) if (!h->d_gbm[q]) {   // the dense form of the two views (row- then column-major), only written by the scenes that do not fit the LDS budget
         int r = dmalloc(&h->d_gbm[q], (size_t)h->caps.max_scenes * 2 * (h->grid_cells / 32));
         if (r) return r;
     }
@@ -272,22 +247,21 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     h->cfg = *cfg; h->caps = *caps; h->device = device;
     if (const char* e = std::getenv("DMPP_PIPELINE_MIN")) h->pipeline_min = std::atoi(e);      // tuning knob: 0 = always, large = never
     auto bail = [&](int code) { pp_destroy(h); return code; };
-    // the search chain gets the highest dispatch priority, the chains that run beside it the lowest: a waiting search
-    // workgroup (80 KB of LDS) must not queue behind the short kernels that fill the gaps
+    // Queue priorities.  The FRONT chain (obstacle snapshot, Decision, Planning) is a short serial chain that every tick's
+    // search waits for: it gets the highest dispatch priority (and its waves raise their issue priority, s_setprio).  The
+    // searches are the bulk of the work and overlap each other: normal priority.  Scoring fills what is left: lowest.
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    const int prio_normal = (prio_least + prio_greatest) / 2;
+    if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_normal) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     h->stream_m[0] = h->stream;
     for (int q = 1; q < kBuf; q++)
-        if (hipStreamCreateWithPriority(&h->stream_m[q], hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
-    // The two side streams (front, score) may use 88 % of the CUs; the rest run nothing but search waves.  The search
-    // needs two 80 KB workgroups per CU and the hardware does not keep the short kernels' workgroups out of its way by
-    // queue priority alone; measured on configs[1] (with the time-keyed launch order): 0.596 ms per tick without the
-    // mask, 0.555 with 224-240 of 256 CUs (200: 0.572, 184: 0.582, 160: 0.654).  DMPP_SIDE_CUS=<n> overrides, 0 = no mask.
+        if (hipStreamCreateWithPriority(&h->stream_m[q], hipStreamNonBlocking, prio_normal) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    // DMPP_SIDE_CUS=<n>: measurement knob - the front and score streams may only use the first n CUs (0 / unset: all of them)
     int side_cus = 0;
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess) { side_cus = prop.multiProcessorCount * 88 / 100; h->n_cus = prop.multiProcessorCount; }
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cus = prop.multiProcessorCount;
         if (const char* e = std::getenv("DMPP_SIDE_CUS")) side_cus = std::atoi(e);
     }
     uint32_t cu_mask[32] = { 0 };
@@ -298,7 +272,7 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     if (side_cus > 0 && hipExtStreamCreateWithCUMask(&h->stream_s, cu_words, cu_mask) != hipSuccess) { (void)hipGetLastError(); h->stream_s = nullptr; }
     if (const char* e = std::getenv("DMPP_OVERLAP")) h->overlap_override = std::atoi(e);
     if (!h->stream_r)
-    if (hipStreamCreateWithPriority(&h->stream_r, hipStreamNonBlocking, prio_least) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithPriority(&h->stream_r, hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     if (!h->stream_s)
     if (hipStreamCreateWithPriority(&h->stream_s, hipStreamNonBlocking, prio_least) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -588,7 +562,7 @@ int pp_plan_tick(pp_handle h)
             }
             h->lds_budget = std::max(64, std::min(want, h->lds_budget_max));
         }
-        const size_t per_wg = sizeof(dmpp::SearchLds) + 64 + (size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget;
+        const size_t per_wg = sizeof(dmpp::SearchLds) + 64 + std::max((size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget, (size_t)h->gbm_lds);
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / per_wg));       // 4 waves per workgroup while it sets up: <= 8 per CU
         h->search_slots = per_cu * std::max(1, h->n_cus);
     } else if (c.grid_stage) {
@@ -601,7 +575,7 @@ int pp_plan_tick(pp_handle h)
     if (h->overlap_override >= 0) overlap = piped && h->overlap_override != 0;      // env DMPP_OVERLAP (measurement knob)
     hipStream_t sm = overlap ? h->stream_m[p] : h->stream;             // search chain
     hipStream_t sf = piped ? h->stream_r : h->stream;                  // front chain
-    hipStream_t ss = piped ? h->stream_s : h->stream;                  // score chain
+    hipStream_t ss = piped ? (overlap ? sm : h->stream_s) : h->stream; // score chain: behind its own search when the searches overlap
     hipStream_t sr = c.grid_stage ? h->stream_r : h->stream;           // Decision + Planning
     if (h->score_recorded[p]) { HIP_TRY(hipStreamWaitEvent(sf, h->ev_score[p], 0)); HIP_TRY(hipStreamWaitEvent(sm, h->ev_score[p], 0)); }
     if (h->search_recorded[p]) HIP_TRY(hipStreamWaitEvent(sf, h->ev_search[p], 0));
@@ -643,38 +617,22 @@ int pp_plan_tick(pp_handle h)
         const int32_t* perm = order_scenes ? h->d_perm[p] : nullptr;
         if (perm && !order_in_front)          // one-stream tick with more scenes than search slots (DMPP_PIPELINE_MIN raised): keyed by the previous tick
             hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[p_prev], h->d_perm[p]);
-        const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
-        const size_t raster_lds = 2 * ((size_t)h->raster_band_rows * c.grid_w / 8);
-        if (h->search_force_gbm) {            // measurement / test knob: every scene on dense bitmaps in HBM
-            Timed t(h, PP_K_FALLBACK, sm);
-            hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), raster_lds, sm, c, n, h->raster_band_rows,
-                               h->d_in, obs_now, h->d_gbm[p], (const int32_t*)nullptr, 0);
-            hipLaunchKernelGGL(dmpp::k_search_gbm, dim3(n), dim3(dmpp::kSearchBlock), (size_t)h->gbm_lds, sm, c, n, h->caps.order_cap, (const int32_t*)nullptr,
-                               h->d_in, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], h->d_cost[p]);
-        } else {
+        {
+            const int budget = h->search_force_gbm ? 0 : h->lds_budget;
             HIP_TRY(hipMemsetAsync(h->d_need[p], 0, sizeof(int32_t), sm));
-            const size_t dyn = (size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget;
+            const size_t dyn = std::max((size_t)h->search_meta_bytes + 8 * (size_t)budget, (size_t)h->gbm_lds);
             {
                 Timed t(h, PP_K_SEARCH, sm);
                 switch (h->search_kind) {
-#define DMPP_LAUNCH_LDS(K)                                                                                                                       \
-                case K: hipLaunchKernelGGL(dmpp::k_search_lds<K>, dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, h->lds_budget, \
-                                           perm, h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p],        \
+#define DMPP_LAUNCH_SEARCH(K)                                                                                                                  \
+                case K: hipLaunchKernelGGL(dmpp::k_search<K>, dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget, perm,  \
+                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], \
                                            h->d_cost[p], h->d_ovf[p], h->d_need[p]); break;
-                DMPP_LAUNCH_LDS(0) DMPP_LAUNCH_LDS(1) DMPP_LAUNCH_LDS(2)
-#undef DMPP_LAUNCH_LDS
+                DMPP_LAUNCH_SEARCH(0) DMPP_LAUNCH_SEARCH(1) DMPP_LAUNCH_SEARCH(2)
+#undef DMPP_LAUNCH_SEARCH
                 }
             }
-            {   // scenes whose obstacle words did not fit the budget (flagged by the kernel above; none in the steady state, and then
-                // both kernels below return at once): dense bitmaps through HBM
-                Timed t(h, PP_K_FALLBACK, sm);
-                hipLaunchKernelGGL(dmpp::k_rasterise, dim3(n, bands), dim3(dmpp::kRasterBlock), raster_lds, sm, c, n, h->raster_band_rows,
-                                   h->d_in, obs_now, h->d_gbm[p], (const int32_t*)h->d_ovf[p], 0);
-                hipLaunchKernelGGL(dmpp::k_search_gbm, dim3(n), dim3(dmpp::kSearchBlock), (size_t)h->gbm_lds, sm, c, n, h->caps.order_cap,
-                                   (const int32_t*)h->d_ovf[p], h->d_in, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p],
-                                   h->d_gbm[p], h->d_cost[p]);
-            }
-            if (!h->lds_budget_fixed) {       // the words the densest scene needed, for the budget of later ticks (read without waiting)
+            if (!h->lds_budget_fixed && !h->search_force_gbm) {       // the words the densest scene needed, for the budget of later ticks (read without waiting)
                 HIP_TRY(hipMemcpyAsync(&h->h_need[p], h->d_need[p], sizeof(int32_t), hipMemcpyDeviceToHost, sm));
                 HIP_TRY(hipEventRecord(h->ev_need[p], sm));
                 h->need_pending[p] = true;
@@ -751,35 +709,38 @@ int pp_get_grid(pp_handle h, int scene, uint8_t* grid)
     const size_t N = (size_t)c.grid_w * c.grid_h;
     // No occupancy grid exists after a tick: the search builds its sparse bitmaps in LDS and drops them.  The grid asked for is
     // produced here, from the obstacle snapshot of the last tick, by the same footprint code (k_export_grid), which also checks
-    // the column-major view against the row-major one.  A scene too dense for one workgroup's LDS goes through k_rasterise.
+    // the column-major view against the row-major one (unless the scene is too dense for one workgroup's LDS).
     HIP_TRY(hipSetDevice(h->device));
     { int r = join_all(h); if (r) return r; }       // the snapshot of the last tick was written on another stream
     const ObPoint* obs_now = h->d_obs_now[h->parity];
-    int bad[2] = { 0, 1 };
-    if (!h->search_force_gbm) {
-        HIP_TRY(hipMemsetAsync(h->d_gridbad, 0, 2 * sizeof(int), h->stream));
-        const size_t dyn = (size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget_max;
-        switch (h->search_kind) {
-        case 0: hipLaunchKernelGGL(dmpp::k_export_grid<0>, dim3(1), dim3(dmpp::kSearchBlock), dyn, h->stream, c, scene, h->lds_budget_max, h->d_in, obs_now, h->d_grid, h->d_gridbad); break;
-        case 1: hipLaunchKernelGGL(dmpp::k_export_grid<1>, dim3(1), dim3(dmpp::kSearchBlock), dyn, h->stream, c, scene, h->lds_budget_max, h->d_in, obs_now, h->d_grid, h->d_gridbad); break;
-        default: hipLaunchKernelGGL(dmpp::k_export_grid<2>, dim3(1), dim3(dmpp::kSearchBlock), dyn, h->stream, c, scene, h->lds_budget_max, h->d_in, obs_now, h->d_grid, h->d_gridbad); break;
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(bad, h->d_gridbad, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (bad[0]) return fail(PP_ERR_STATE, "pp_get_grid: the row-major and column-major views of the scene differ in " + std::to_string(bad[0]) + " cell(s)");
+    int bad[2] = { 0, 0 };
+    HIP_TRY(hipMemsetAsync(h->d_gridbad, 0, 2 * sizeof(int), h->stream));
+    const int budget = h->search_force_gbm ? 1 : h->lds_budget_max;      // (1 word: nothing fits, the span-by-span path)
+    const size_t dyn = (size_t)h->search_meta_bytes + 8 * (size_t)budget;
+    switch (h->search_kind) {
+    case 0: hipLaunchKernelGGL(dmpp::k_export_grid<0>, dim3(1), dim3(dmpp::kSearchBlock), dyn, h->stream, c, scene, budget, h->d_in, obs_now, h->d_grid, h->d_gridbad); break;
+    case 1: hipLaunchKernelGGL(dmpp::k_export_grid<1>, dim3(1), dim3(dmpp::kSearchBlock), dyn, h->stream, c, scene, budget, h->d_in, obs_now, h->d_grid, h->d_gridbad); break;
+    default: hipLaunchKernelGGL(dmpp::k_export_grid<2>, dim3(1), dim3(dmpp::kSearchBlock), dyn, h->stream, c, scene, budget, h->d_in, obs_now, h->d_grid, h->d_gridbad); break;
     }
-    if (bad[1]) {
-        const int bands = (c.grid_h + h->raster_band_rows - 1) / h->raster_band_rows;
-        const size_t lds = 2 * ((size_t)h->raster_band_rows * c.grid_w / 8);
-        uint32_t* gb = h->d_gbm[h->parity];
-        hipLaunchKernelGGL(dmpp::k_rasterise, dim3(1, bands), dim3(dmpp::kRasterBlock), lds, h->stream, c, h->n_scenes, h->raster_band_rows,
-                           h->d_in, obs_now, gb, (const int32_t*)nullptr, scene);
-        hipLaunchKernelGGL(dmpp::k_expand_grid, dim3((unsigned)((N / 16 + dmpp::kRasterBlock - 1) / dmpp::kRasterBlock)), dim3(dmpp::kRasterBlock), 0,
-                           h->stream, c.grid_w, c.grid_h, gb + (size_t)scene * 2 * (N / 32), h->d_grid);
-        HIP_TRY(hipGetLastError());
-    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(bad, h->d_gridbad, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (bad[0]) return fail(PP_ERR_STATE, "pp_get_grid: the row-major and column-major views of the scene differ in " + std::to_string(bad[0]) + " cell(s)");
     return fetch(h, grid, h->d_grid, N);
+}
+int pp_get_search_info(pp_handle h, int32_t* lds_budget_words, int32_t* need_words, int32_t* dense_scenes)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    if (!h->d_ovf[0]) return fail(PP_ERR_STATE, "handle was created without the grid stage");
+    if (lds_budget_words) *lds_budget_words = h->search_force_gbm ? 0 : h->lds_budget;
+    if (need_words) *need_words = h->need_seen;
+    if (dense_scenes) {
+        std::vector<int32_t> ovf((size_t)std::max(h->n_scenes, 1));
+        int r = fetch(h, ovf.data(), h->d_ovf[h->parity], (size_t)h->n_scenes * sizeof(int32_t)); if (r) return r;
+        int k = 0; for (int i = 0; i < h->n_scenes; i++) k += ovf[(size_t)i] != 0;
+        *dense_scenes = k;
+    }
+    return PP_OK;
 }
 int pp_get_order(pp_handle h, int scene, int32_t* order, int cap)
 {
@@ -1071,7 +1032,6 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes)
 }
 void* pp_stream(pp_handle h) { return h ? (void*)h->stream : nullptr; }
 
-int pp_raster_band_rows(int grid_h, int n_scenes) { return raster_band_rows_for(grid_h, n_scenes, 128); }
 
 size_t pp_sizeof(int which)
 {

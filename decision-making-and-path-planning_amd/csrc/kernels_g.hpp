@@ -1,115 +1,15 @@
 // kernels_g.hpp — HIP kernels of the grid engine (specification in
 // DESIGN.md §5 and oracle/dmpp_grid_oracle.c — the reference has no grid code).
 //
-//   k_rasterise : obstacle list -> bit-packed occupancy grid in HBM, row-major and column-major, for the scenes whose
-//                 search runs on dense bitmaps (k_search_gbm: the fallback of kernels_s.hpp).  One workgroup per (scene,
-//                 band of rows): footprints are OR-ed into two LDS bit bands, then written out word by word.
-//   k_expand_grid: one scene's bitmap -> u8 grid, on demand (pp_get_grid of a scene too dense for k_export_grid).
 //   k_order     : launch order of the search, heaviest scenes first (counting sort on the previous search times).
 //   k_score     : lattice candidates (cubic Beziers to laterally shifted terminals + the grid
 //                 path) scored on collision / curvature / progress, 4 (or 16) waves per scene.
-// The search itself (and the rasterisation it does for itself) is kernels_s.hpp.
+// The search itself, and the rasterisation (G1) it does for itself, is kernels_s.hpp.
 #pragma once
 #include "dev_geom.hpp"
 #include "kernels_s.hpp"
 
 namespace dmpp {
-
-// ---------------------------------------------------------------------------------------
-// G1.  grid: per scene H x W/32 words row-major, then W x H/32 words column-major; bit = 1 occupied (the host
-// guarantees W % 32 == 0 and H % 32 == 0, and bands of a multiple of 32 rows: whole words in both orientations).
-constexpr int kRasterBlock = 256;
-
-__global__ void __launch_bounds__(kRasterBlock)
-k_rasterise(PlannerConfig c, int n_scenes, int band_rows, const SceneIn* __restrict__ in,
-            const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gbits, const int32_t* __restrict__ only, int scene0)
-{
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int scene = scene0 + blockIdx.x, band = blockIdx.y;
-    if (scene >= n_scenes) return;
-    if (only && !only[scene]) return;            // dense bitmaps are only needed by the scenes k_search_lds handed on
-    const int W = c.grid_w, H = c.grid_h, WW = W >> 5, HW = H >> 5;
-    const int row0 = band * band_rows;                               // band_rows is a multiple of 32
-    const int rows = min(band_rows, H - row0);
-    if (rows <= 0) return;
-    const int words = (rows * W) >> 5;
-    const int bw = rows >> 5;                                        // words per column inside this band
-    uint32_t* bits = reinterpret_cast<uint32_t*>(smem_raw);          // row-major band: rows x WW words
-    uint32_t* bitsT = bits + ((band_rows * W) >> 5);                 // column-major band: W x bw words
-    const int tid = threadIdx.x;
-    for (int w = tid; w < words; w += kRasterBlock) { bits[w] = 0; bitsT[w] = 0; }
-    __syncthreads();
-    const SceneIn& si = in[scene];
-    const double ox = si.grid_origin.x, oy = si.grid_origin.y;
-    const int m = si.obs_n;
-    const ObPoint* obs = obs_now + si.obs_off;
-    // Footprints that touch this band: one thread per obstacle computes the clipped bounding box once,
-    // the hits are compacted into an LDS list (chunks of 256 obstacles); then, per listed footprint, the
-    // cells of its box are spread over the 256 threads.
-    __shared__ int s_box[kRasterBlock][4];
-    __shared__ double s_par[kRasterBlock][3];      // x, y, R^2
-    __shared__ int s_cnt;
-    for (int j0 = 0; j0 < m; j0 += kRasterBlock) {
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        const int j = j0 + tid;
-        if (j < m) {
-            const ObPoint o = obs[j];
-            const double R = (double)o.radius + c.inflate;
-            int ix0 = (int)floor((o.x - R - ox) / c.cell) - 1, ix1 = (int)floor((o.x + R - ox) / c.cell) + 1;
-            int iy0 = (int)floor((o.y - R - oy) / c.cell) - 1, iy1 = (int)floor((o.y + R - oy) / c.cell) + 1;
-            ix0 = max(ix0, 0); ix1 = min(ix1, W - 1);
-            iy0 = max(iy0, row0); iy1 = min(iy1, row0 + rows - 1);
-            if (ix1 >= ix0 && iy1 >= iy0) {
-                const int k = atomicAdd(&s_cnt, 1);        // order does not matter: the bits are OR-ed
-                s_box[k][0] = ix0; s_box[k][1] = ix1; s_box[k][2] = iy0; s_box[k][3] = iy1;
-                s_par[k][0] = o.x; s_par[k][1] = o.y; s_par[k][2] = R * R;
-            }
-        }
-        __syncthreads();
-        const int nhit = s_cnt;
-        for (int k = 0; k < nhit; k++) {
-            const int ix0 = s_box[k][0], iy0 = s_box[k][2];
-            const int bwid = s_box[k][1] - ix0 + 1, bh = s_box[k][3] - iy0 + 1;
-            const double cxo = s_par[k][0], cyo = s_par[k][1], R2 = s_par[k][2];
-            for (int t = tid; t < bwid * bh; t += kRasterBlock) {
-                const int iy = iy0 + t / bwid, ix = ix0 + t % bwid;
-                const double cx = ox + ((double)ix + 0.5) * c.cell, cy = oy + ((double)iy + 0.5) * c.cell;
-                const double dx = cx - cxo, dy = cy - cyo;
-                if (dx * dx + dy * dy <= R2) {
-                    const int r = iy - row0, b = r * W + ix;
-                    atomicOr(&bits[b >> 5], 1u << (b & 31));
-                    atomicOr(&bitsT[ix * bw + (r >> 5)], 1u << (r & 31));     // the same cell in the column-major copy
-                }
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    // the occupancy grid, bit-packed: row-major (H x WW words) then column-major (W x HW words)
-    uint32_t* brow = gbits + (size_t)scene * 2 * ((size_t)(W * H) >> 5);
-    uint32_t* bcol = brow + ((size_t)(W * H) >> 5);
-    for (int w = tid; w < words; w += kRasterBlock) brow[row0 * WW + w] = bits[w];
-    for (int w = tid; w < words; w += kRasterBlock) bcol[(w / bw) * HW + (row0 >> 5) + (w % bw)] = bitsT[w];
-}
-
-// The occupancy grid of one scene as bytes (0 free / 1 occupied), for pp_get_grid: 16 bits -> 16 bytes per thread.
-__global__ void __launch_bounds__(kRasterBlock)
-k_expand_grid(int grid_w, int grid_h, const uint32_t* __restrict__ brow, uint8_t* __restrict__ out)
-{
-    const int chunks = (grid_w * grid_h) >> 4;
-    uint4* o4 = reinterpret_cast<uint4*>(out);
-    for (int k = blockIdx.x * kRasterBlock + threadIdx.x; k < chunks; k += gridDim.x * kRasterBlock) {
-        const uint32_t w = brow[k >> 1];
-        const uint32_t h16 = (k & 1) ? (w >> 16) : (w & 0xFFFFu);
-        uint4 v;
-        v.x = ((h16 & 0xFu) * 0x00204081u) & 0x01010101u;
-        v.y = (((h16 >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
-        v.z = (((h16 >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
-        v.w = (((h16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u;
-        o4[k] = v;
-    }
-}
 
 // Launch order of the scenes of k_search: heaviest first, by the time the scene's search took on the previous tick (in
 // units of 8 Ki cycles, written by k_search; it changes little from tick to tick).  One wave per scene and two waves per CU means the kernel ends with its

@@ -26,6 +26,7 @@ k_effective_obstacles(PlannerConfig c, int n_scenes, const SceneIn* __restrict__
 {
     const int s = blockIdx.x;
     if (s >= n_scenes) return;
+    __builtin_amdgcn_s_setprio(3);             // the front chain is short and every search waits for it: issue ahead of the searching waves
     const int off = in[s].obs_off, m = in[s].obs_n;
     const double t = c.dyn_dt * (double)st[s].tick;
     for (int j = threadIdx.x; j < m; j += kBlock) {
@@ -349,6 +350,7 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     DecShared& sh = *reinterpret_cast<DecShared*>(smem_raw);
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
+    __builtin_amdgcn_s_setprio(3);             // front chain: ahead of the searching waves on the same SIMD
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const SceneIn& si = in[scene];
     SceneState& st = state[scene];
@@ -644,6 +646,7 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     PlanShared& sh = *reinterpret_cast<PlanShared*>(smem_raw);
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
+    __builtin_amdgcn_s_setprio(3);             // front chain: ahead of the searching waves on the same SIMD
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const SceneIn& si = in[scene];
     SceneState& st = state[scene];

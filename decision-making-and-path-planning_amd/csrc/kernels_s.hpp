@@ -1,15 +1,14 @@
 // kernels_s.hpp — G2, the jump-point A* of the grid engine (specification: oracle/dmpp_grid_oracle.c, DESIGN.md §5;
 // the reference has no grid code).  ONE searching wave per scene.
 //
-//   k_search_lds<K> : the scene's workgroup (4 waves) rasterises its own obstacle list straight into LDS as a SPARSE
-//                     two-view bitmap - row-major for E/W scans, column-major for N/S scans; per line a mask of the
-//                     words that hold an obstacle bit and the index of the line's first stored word (per-line CSR);
-//                     only non-zero words are stored.  No occupancy grid crosses HBM on this path, and a scene needs
-//                     ~12 KB (64 obstacles) instead of 64 KB of bitmaps, whatever the grid size.  Then wave 0 searches.
-//   k_search_gbm    : the same search on a dense bitmap in HBM (written by k_rasterise) with the line masks in LDS -
-//                     only for scenes whose non-zero words do not fit the launch's LDS budget (flagged by k_search_lds).
+//   k_search<K> : the scene's workgroup (4 waves) rasterises its own obstacle list straight into LDS as a SPARSE two-view
+//                 bitmap - row-major for E/W scans, column-major for N/S scans; per line a mask of the words that hold an
+//                 obstacle bit and the index of the line's first stored word (per-line CSR); only non-zero words are stored.
+//                 No occupancy grid crosses HBM, and a scene needs ~12 KB (64 obstacles) instead of 64 KB of bitmaps,
+//                 whatever the grid size.  Then wave 0 searches.  A scene whose non-zero words do not fit the launch's LDS
+//                 budget writes the DENSE form of the two views to HBM instead and is searched there, by the same loop.
 //
-// The search loop (search_core) is shared:
+// The search loop (search_core) is shared by the two forms:
 //   * a straight jump is ONE lane (jump_lane): it visits, in travel order, only the words where the line or one of its
 //     two neighbours has an obstacle bit (or the goal) and builds  blocked | forced | goal  with two shifts;
 //   * a diagonal jump (<= DMPP_DIAG_JUMP cells) is a group of 16 lanes: lane pair k scans horizontally | vertically from
@@ -309,81 +308,79 @@ __device__ __forceinline__ int block_excl_scan(int v, int tid, int* s_wave /* [k
     return base + incl - v;
 }
 
-// Builds both sparse views of a scene from its obstacle list.  All kSearchBlock threads; returns the words the larger view
-// needs (> budget: nothing was filled, the views are unusable).
-//   pass 1: which words of which lines the footprints touch (exact spans: the line masks say exactly which words are non-zero);
-//   offsets: exclusive prefix sum of the word counts over the lines;  pass 2: the same spans again, OR-ed into the words.
+// Walks the exact spans of every footprint of a scene: emit(colhalf, line, a, b) is called, by the lane that owns the line,
+// for every line a footprint touches, [a, b] being its first and last occupied position on that line (row-major half:
+// line = y, positions x; column-major half: line = x, positions y).  All kSearchBlock threads.
 // A wave owns the obstacles wv, wv + 4, ...; it computes 64 footprints at once (one per lane: the divisions are paid once
 // per obstacle, not per line) and then walks them, lanes 0..31 on a footprint's rows and lanes 32..63 on its columns.
+template <class Emit>
+__device__ __forceinline__ void for_each_span(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m, Emit&& emit)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int W = c.grid_w, H = c.grid_h;
+    const bool colhalf = lane >= 32;
+    const int l32 = lane & 31;
+    const double cell = c.cell, inv_cell = 1.0 / c.cell;
+    const GlobalPoint2D origin = si.grid_origin;
+    const double org_u = colhalf ? origin.y : origin.x, org_v = colhalf ? origin.x : origin.y;
+    auto bcast_d = [](double v, int src) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    };
+    for (int base = 0; base < m; base += kSearchSetupWaves * DMPP_WAVE) {
+        // this lane's obstacle of the chunk
+        Footprint f; f.ox = f.oy = f.R2 = 0; f.ix0 = f.iy0 = 0; f.ix1 = f.iy1 = -1;
+        int icx = 0, icy = 0;
+        const int j = base + wv + kSearchSetupWaves * lane;
+        if (j < m) {
+            f = footprint_of(c, origin, obs[j], W, H);
+            icx = (int)floor((f.ox - origin.x) / cell);
+            icy = (int)floor((f.oy - origin.y) / cell);
+        }
+        const unsigned long long anym = __ballot(j < m && f.ix1 >= f.ix0 && f.iy1 >= f.iy0);
+        const int left = m - base - wv;
+        const int cnt = left <= 0 ? 0 : min(DMPP_WAVE, (left + kSearchSetupWaves - 1) / kSearchSetupWaves);
+        for (int q = 0; q < cnt; q++) {
+            if (!((anym >> q) & 1ull)) continue;
+            const double fx = bcast_d(f.ox, q), fy = bcast_d(f.oy, q), R2 = bcast_d(f.R2, q);
+            const int ix0 = __builtin_amdgcn_readlane(f.ix0, q), ix1 = __builtin_amdgcn_readlane(f.ix1, q);
+            const int iy0 = __builtin_amdgcn_readlane(f.iy0, q), iy1 = __builtin_amdgcn_readlane(f.iy1, q);
+            const int jcx = __builtin_amdgcn_readlane(icx, q), jcy = __builtin_amdgcn_readlane(icy, q);
+            const double ou = colhalf ? fy : fx, ov = colhalf ? fx : fy;
+            const int ic = colhalf ? jcy : jcx, l0 = colhalf ? ix0 : iy0, l1 = colhalf ? ix1 : iy1, lo = colhalf ? iy0 : ix0, hi = colhalf ? iy1 : ix1;
+            for (int l = l0 + l32; l <= l1; l += 32) {
+                const double dv = (org_v + ((double)l + 0.5) * cell) - ov;
+                int a, b;
+                if (exact_span(ou, org_u, cell, inv_cell, dv * dv, R2, ic, lo, hi, a, b)) emit(colhalf, l, a, b);
+            }
+        }
+    }
+}
+
+// Builds both sparse views of a scene from its obstacle list.  All kSearchBlock threads; returns the words the larger view
+// needs (> budget: nothing was filled, the views are unusable).
+//   pass 1: which words of which lines the footprints touch (the line masks say exactly which words are non-zero);
+//   offsets: exclusive prefix sum of the word counts over the lines;  pass 2: the same spans again, OR-ed into the words.
 template <int K>
 __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m,
                                                   const SparseView<K>& vr, const SparseView<K>& vc, int budget, int* s_wave,
                                                   long long* tmark = nullptr)
 {
     using M = typename SparseView<K>::M;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
+    const int W = c.grid_w, H = c.grid_h;
     int tm_i = 0;
     auto mark = [&]() { if (tmark) tmark[tm_i++] = clock64(); };
     mark();
-    const int W = c.grid_w, H = c.grid_h;
-    const bool colhalf = lane >= 32;                        // lanes 0..31: rows of the footprint, 32..63: its columns
-    const int l32 = lane & 31;
-    const double inv_cell = 1.0 / c.cell;
-    const double org_u = colhalf ? si.grid_origin.y : si.grid_origin.x, org_v = colhalf ? si.grid_origin.x : si.grid_origin.y;
     for (int l = tid; l < H; l += kSearchBlock) vr.clear_line(l);
     for (int l = tid; l < W; l += kSearchBlock) vc.clear_line(l);
     __syncthreads();
-
-    struct Lanes { Footprint f; int icx, icy; bool any; };
-    auto footprints_of_chunk = [&](int base) {              // this lane's obstacle of the chunk that starts at `base`
-        Lanes q; q.any = false; q.icx = q.icy = 0;
-        q.f.ox = q.f.oy = q.f.R2 = 0; q.f.ix0 = q.f.iy0 = 0; q.f.ix1 = q.f.iy1 = -1;
-        const int j = base + wv + kSearchSetupWaves * lane;
-        if (j < m) {
-            q.f = footprint_of(c, si.grid_origin, obs[j], W, H);
-            q.any = q.f.ix1 >= q.f.ix0 && q.f.iy1 >= q.f.iy0;
-            q.icx = (int)floor((q.f.ox - si.grid_origin.x) / c.cell);
-            q.icy = (int)floor((q.f.oy - si.grid_origin.y) / c.cell);
-        }
-        return q;
-    };
-    auto bcast_d = [](double v, int src) {
-        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-        return __hiloint2double(hi, lo);
-    };
-    // fn(ou, ov, R2, ic, l0, l1, lo, hi): one footprint seen from this lane's half (u along the lines, v across them)
-    auto walk = [&](const Lanes& mine, int base, auto&& fn) {
-        const int left = m - base - wv;
-        const int cnt = left <= 0 ? 0 : min(DMPP_WAVE, (left + kSearchSetupWaves - 1) / kSearchSetupWaves);
-        const unsigned long long anym = __ballot(mine.any);
-        for (int q = 0; q < cnt; q++) {
-            if (!((anym >> q) & 1ull)) continue;
-            const double fx = bcast_d(mine.f.ox, q), fy = bcast_d(mine.f.oy, q), R2 = bcast_d(mine.f.R2, q);
-            const int ix0 = __builtin_amdgcn_readlane(mine.f.ix0, q), ix1 = __builtin_amdgcn_readlane(mine.f.ix1, q);
-            const int iy0 = __builtin_amdgcn_readlane(mine.f.iy0, q), iy1 = __builtin_amdgcn_readlane(mine.f.iy1, q);
-            const int icx = __builtin_amdgcn_readlane(mine.icx, q), icy = __builtin_amdgcn_readlane(mine.icy, q);
-            fn(colhalf ? fy : fx, colhalf ? fx : fy, R2, colhalf ? icy : icx, colhalf ? ix0 : iy0, colhalf ? ix1 : iy1,
-               colhalf ? iy0 : ix0, colhalf ? iy1 : ix1);
-        }
-    };
-    const int chunk = kSearchSetupWaves * DMPP_WAVE;
-    mark();
-    const Lanes first = footprints_of_chunk(0);             // kept in registers for pass 2 (the usual case: <= 256 obstacles)
-    mark();
-    // ---- pass 1 ----
-    for (int base = 0; base < m; base += chunk) {
-        const Lanes cur = base == 0 ? first : footprints_of_chunk(base);
-        walk(cur, base, [&](double ou, double ov, double R2, int ic, int l0, int l1, int lo, int hi) {
-            for (int l = l0 + l32; l <= l1; l += 32) {
-                const double dv = (org_v + ((double)l + 0.5) * c.cell) - ov;
-                int a, b;
-                if (!exact_span(ou, org_u, c.cell, inv_cell, dv * dv, R2, ic, lo, hi, a, b)) continue;
-                const int wa = a >> 5, wb = b >> 5;
-                const M bits = (M)((((M)2) << (wb - wa)) - (M)1) << wa;
-                if (colhalf) vc.or_mask(l, bits); else vr.or_mask(l, bits);
-            }
-        });
-    }
+    mark(); mark();
+    for_each_span(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
+        const int wa = a >> 5, wb = b >> 5;
+        const M bits = (M)((((M)2) << (wb - wa)) - (M)1) << wa;
+        if (colhalf) vc.or_mask(l, bits); else vr.or_mask(l, bits);
+    });
     __syncthreads();
     mark();
     // ---- offsets: exclusive prefix sum of the word counts over the lines, per view ----
@@ -406,25 +403,51 @@ __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const 
     for (int i = tid; i < total_c; i += kSearchBlock) vc.data[i] = 0;
     __syncthreads();
     mark();
-    // ---- pass 2: the exact spans ----
-    const SparseView<K> vw = colhalf ? vc : vr;             // by value: per-lane field selects, no stack object
-    for (int base = 0; base < m; base += chunk) {
-        const Lanes cur = base == 0 ? first : footprints_of_chunk(base);
-        walk(cur, base, [&](double ou, double ov, double R2, int ic, int l0, int l1, int lo, int hi) {
-            for (int l = l0 + l32; l <= l1; l += 32) {
-                const double dv = (org_v + ((double)l + 0.5) * c.cell) - ov;
-                int a, b;
-                if (!exact_span(ou, org_u, c.cell, inv_cell, dv * dv, R2, ic, lo, hi, a, b)) continue;
-                const LineM<M> lm = vw.line(l);
-                for_words(a, b, [&](int w, uint32_t bits) {
-                    __hip_atomic_fetch_or(&vw.data[lm.off + popc_m((M)(lm.mask & ((((M)1) << w) - (M)1)))], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                });
-            }
+    for_each_span(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
+        const SparseView<K> vw = colhalf ? vc : vr;          // by value: per-lane field selects, no stack object
+        const LineM<M> lm = vw.line(l);
+        for_words(a, b, [&](int w, uint32_t bits) {
+            __hip_atomic_fetch_or(&vw.data[lm.off + popc_m((M)(lm.mask & ((((M)1) << w) - (M)1)))], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         });
-    }
+    });
     __syncthreads();
     mark();
     return need;
+}
+
+// The dense form of the same two views, in HBM: H x W/32 words row-major at bm, W x H/32 words column-major behind them;
+// one u64 per line in LDS says which words are non-zero.  Only for the scenes whose non-zero words do not fit the LDS
+// budget of the launch.  All kSearchBlock threads.
+__device__ __forceinline__ void build_dense_views(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m,
+                                                  uint32_t* __restrict__ bm, DMPP_LDS uint64_t* nz_row, DMPP_LDS uint64_t* nz_col)
+{
+    const int tid = threadIdx.x;
+    const int W = c.grid_w, H = c.grid_h, WW = W >> 5, HW = H >> 5, NW = (W * H) >> 5;
+    uint32_t* bmT = bm + NW;
+    {
+        uint4* z4 = reinterpret_cast<uint4*>(bm);
+        const uint4 z = { 0u, 0u, 0u, 0u };
+        for (int i = tid; i < (2 * NW) >> 2; i += kSearchBlock) z4[i] = z;
+    }
+    __threadfence();
+    __syncthreads();
+    for_each_span(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
+        uint32_t* line = colhalf ? bmT + (size_t)l * HW : bm + (size_t)l * WW;
+        for_words(a, b, [&](int w, uint32_t bits) { atomicOr(&line[w], bits); });
+    });
+    __threadfence();
+    __syncthreads();
+    for (int v = 0; v < 2; v++) {
+        const uint32_t* src = v ? bmT : bm;
+        DMPP_LDS uint64_t* nz = v ? nz_col : nz_row;
+        const int LW = v ? HW : WW, NL = v ? W : H;
+        for (int line = tid; line < NL; line += kSearchBlock) {
+            uint64_t msk = 0;
+            for (int w = 0; w < LW; w++) msk |= (uint64_t)min(src[line * LW + w], 1u) << w;
+            nz[line] = msk;
+        }
+    }
+    __syncthreads();
 }
 
 // clears one cell in a sparse view (the start cell is always free)
@@ -915,15 +938,18 @@ __device__ __forceinline__ void publish_debug(int32_t* path, int max_path, const
 #endif
 
 // ---------------------------------------------------------------------------------------
-// The usual search kernel.  Dynamic LDS: the line metas of both views, then `budget` data words per view.
-//   overflow[scene] = 1 when the scene's non-zero words do not fit `budget` (k_search_gbm then runs it), else 0;
+// The search kernel.  Dynamic LDS: the line metas of both sparse views, then `budget` data words per view (and at least
+// (W + H) * 8 bytes: the line masks of the dense form).
+//   A scene whose non-zero words fit `budget` is searched on the sparse views in LDS; one that does not fit (overflow[scene]
+//   = 1) rasterises the dense form into gbitmaps (HBM) and is searched there - same loop, slower reads.  budget = 0 sends
+//   every scene that way (test knob).
 //   need_max: running maximum of the words a scene needed (the host sizes the next launches from it).
 template <int K>
 __global__ void __launch_bounds__(kSearchBlock)
-k_search_lds(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
-             const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
-             int32_t* __restrict__ paths, GridOut* __restrict__ gout, int32_t* __restrict__ cost_out, int32_t* __restrict__ overflow,
-             int32_t* __restrict__ need_max)
+k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
+         const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
+         int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out,
+         int32_t* __restrict__ overflow, int32_t* __restrict__ need_max)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ SearchLds L;
@@ -954,22 +980,36 @@ k_search_lds(PlannerConfig c, int n_scenes, int order_cap, int budget, const int
     }
     for (int i = tid; i < kClosedTab; i += kSearchBlock) L.c_tab[i] = 0;
     for (int i = tid; i < kOpenCap; i += kSearchBlock) L.o_f2[i] = 0xFFFFu;      // dead slots everywhere: the pop never range-checks
+    const ObPoint* obs = obs_now + si.obs_off;
 #ifdef DMPP_DEBUG_SEARCH
     long long tmark[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    const int need = build_sparse_views<K>(c, si, obs_now + si.obs_off, si.obs_n, vr, vc, budget, L.s_wave, tmark);
+    const int need = budget > 0 ? build_sparse_views<K>(c, si, obs, si.obs_n, vr, vc, budget, L.s_wave, tmark) : 1;
 #else
-    const int need = build_sparse_views<K>(c, si, obs_now + si.obs_off, si.obs_n, vr, vc, budget, L.s_wave);
+    const int need = budget > 0 ? build_sparse_views<K>(c, si, obs, si.obs_n, vr, vc, budget, L.s_wave) : 1;
 #endif
-    if (tid == 0) { atomicMax(need_max, need); overflow[scene] = need > budget ? 1 : 0; }
-    if (need > budget) return;                 // this scene goes to k_search_gbm (uniform over the block)
+    const bool dense = need > budget;          // uniform over the block
+    if (tid == 0) { if (budget > 0) atomicMax(need_max, need); overflow[scene] = dense ? 1 : 0; }
+    uint32_t* bm = gbitmaps + (size_t)scene * 2 * (N >> 5);
+    DMPP_LDS uint64_t* nz_row = (DMPP_LDS uint64_t*)smem_raw;
+    DMPP_LDS uint64_t* nz_col = nz_row + H;
+    if (dense) { __syncthreads(); build_dense_views(c, si, obs, si.obs_n, bm, nz_row, nz_col); }
+    const DenseView dr{ bm, nz_row, WW, H }, dc{ bm + (N >> 5), nz_col, HW, W };
     const int start = cell_of(c, si.grid_origin, si.loc.globalpoint.x, si.loc.globalpoint.y);
     const int goal = cell_of(c, si.grid_origin, si.goal.x, si.goal.y);
-    const bool goal_blocked = cell_blocked(vr, goal % W, goal / W);       // the same in every wave
+    const bool goal_blocked = dense ? cell_blocked(dr, goal % W, goal / W) : cell_blocked(vr, goal % W, goal / W);       // the same in every wave
+    __syncthreads();
     if (!goal_blocked && tid == 0) {                                      // the vehicle is where it is
-        sparse_clear_cell(vr, start / W, start % W);
-        sparse_clear_cell(vc, start % W, start / W);
-        L.o_ent[0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
-        L.o_f2[0] = (uint16_t)(hfun(start % W, start / W, goal % W, goal / W) >> 1);
+        const int sx = start % W, sy = start / W;
+        if (dense) {
+            bm[start >> 5] &= ~(1u << (start & 31));
+            bm[(N >> 5) + sx * HW + (sy >> 5)] &= ~(1u << (sy & 31));
+            __threadfence();
+        } else {
+            sparse_clear_cell(vr, sy, sx);
+            sparse_clear_cell(vc, sx, sy);
+        }
+        L.o_ent[0] = (uint32_t)sx | ((uint32_t)sy << 12) | (8u << 24);
+        L.o_f2[0] = (uint16_t)(hfun(sx, sy, goal % W, goal / W) >> 1);
         L.o_run[0] = 0;
     }
     __syncthreads();
@@ -978,22 +1018,21 @@ k_search_lds(PlannerConfig c, int n_scenes, int order_cap, int budget, const int
     const long long t_setup = clock64() - t_begin;
     SearchOut R; R.status = DMPP_G_GOAL_BLOCKED; R.n_exp = 0; R.n_push = 0; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
     int32_t* path = paths + (size_t)scene * c.max_path;
+    uint32_t* closed = gclosed + (size_t)scene * (N >> 5);
+    uint16_t* pin = pinfo + (size_t)scene * N;
+    int32_t* order = orders ? orders + (size_t)scene * order_cap : nullptr;
 #ifdef DMPP_DEBUG_SEARCH
     long long dbg_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int dbg_c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#endif
-    if (!goal_blocked)
-        R = search_core(c, L, vr, vc, start, goal, order_cap, gclosed + (size_t)scene * (N >> 5), pinfo + (size_t)scene * N,
-                        orders ? orders + (size_t)scene * order_cap : nullptr, path, lane
-#ifdef DMPP_DEBUG_SEARCH
-                        , dbg_t, dbg_c
-#endif
-                        );
-#ifdef DMPP_DEBUG_SEARCH
+    if (!goal_blocked) R = dense ? search_core(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, lane, dbg_t, dbg_c)
+                                 : search_core(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, lane, dbg_t, dbg_c);
     if (lane == 0) {
         publish_debug(path, c.max_path, dbg_t, dbg_c, t_setup, clock64() - t_begin);
-        int32_t* d2 = path + c.max_path - 32;      // set-up phases: entry->clear, footprints, pass 1, offsets, zero, pass 2, tail
+        int32_t* d2 = path + c.max_path - 32;      // set-up phases: entry->clear, (unused x2), pass 1, offsets, zero, pass 2, tail
         d2[0] = (int)(tmark[0] - t_begin); for (int i = 1; i < 7; i++) d2[i] = (int)(tmark[i] - tmark[i - 1]); d2[7] = (int)(t_begin + t_setup - tmark[6]);
     }
+#else
+    if (!goal_blocked) R = dense ? search_core(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, lane)
+                                 : search_core(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, lane);
 #endif
     (void)t_setup;
     if (lane == 0) {
@@ -1002,88 +1041,10 @@ k_search_lds(PlannerConfig c, int n_scenes, int order_cap, int budget, const int
     }
 }
 
-// The same search on the dense bitmaps k_rasterise wrote to HBM (row-major then column-major per scene), one u64 mask per
-// line in dynamic LDS.  Runs the scenes flagged in `overflow` (all scenes when it is null).
-__global__ void __launch_bounds__(kSearchBlock)
-k_search_gbm(PlannerConfig c, int n_scenes, int order_cap, const int32_t* __restrict__ overflow, const SceneIn* __restrict__ in,
-             uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders, int32_t* __restrict__ paths,
-             GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out)
-{
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ SearchLds L;
-    const int scene = blockIdx.x;
-    if (scene >= n_scenes) return;
-    if (overflow && !overflow[scene]) return;
-    const long long t_begin = clock64();
-    __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x, lane = tid & (DMPP_WAVE - 1), wv = tid >> 6;
-    const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5, HW = H >> 5;
-    const SceneIn& si = in[scene];
-    DMPP_LDS uint64_t* nz_row = (DMPP_LDS uint64_t*)smem_raw;
-    DMPP_LDS uint64_t* nz_col = nz_row + H;
-    uint32_t* bm = gbitmaps + (size_t)scene * 2 * (N >> 5);
-    uint32_t* bmT = bm + (N >> 5);
-    const int start = cell_of(c, si.grid_origin, si.loc.globalpoint.x, si.loc.globalpoint.y);
-    const int goal = cell_of(c, si.grid_origin, si.goal.x, si.goal.y);
-    const bool goal_blocked = ((bm[goal >> 5] >> (goal & 31)) & 1u) != 0;      // the same in every wave
-    if (!goal_blocked) {
-        if (tid == 0) {                                                     // the vehicle is where it is
-            const int sx = start % W, sy = start / W;
-            bm[start >> 5] &= ~(1u << (start & 31));
-            bmT[sx * HW + (sy >> 5)] &= ~(1u << (sy & 31));
-        }
-        __threadfence();
-        __syncthreads();
-        // line masks of both views (bit w = word w of the line is non-zero): one lane per line
-        for (int v = 0; v < 2; v++) {
-            const uint32_t* src = v ? bmT : bm;
-            DMPP_LDS uint64_t* nz = v ? nz_col : nz_row;
-            const int LW = v ? HW : WW, NL = v ? W : H;
-            for (int line = tid; line < NL; line += kSearchBlock) {
-                uint64_t msk = 0;
-                for (int w = 0; w < LW; w++) msk |= (uint64_t)min(src[line * LW + w], 1u) << w;
-                nz[line] = msk;
-            }
-        }
-        for (int i = tid; i < kClosedTab; i += kSearchBlock) L.c_tab[i] = 0;
-        for (int i = tid; i < kOpenCap; i += kSearchBlock) L.o_f2[i] = 0xFFFFu;
-        __syncthreads();
-        if (tid == 0) {
-            L.o_ent[0] = (uint32_t)(start % W) | ((uint32_t)(start / W) << 12) | (8u << 24);
-            L.o_f2[0] = (uint16_t)(hfun(start % W, start / W, goal % W, goal / W) >> 1);
-            L.o_run[0] = 0;
-        }
-    }
-    __syncthreads();
-    if (wv != 0) return;
-    const long long t_setup = clock64() - t_begin;
-    SearchOut R; R.status = DMPP_G_GOAL_BLOCKED; R.n_exp = 0; R.n_push = 0; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
-    int32_t* path = paths + (size_t)scene * c.max_path;
-#ifdef DMPP_DEBUG_SEARCH
-    long long dbg_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int dbg_c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#endif
-    if (!goal_blocked) {
-        const DenseView Vrow{ bm, nz_row, WW, H }, Vcol{ bmT, nz_col, HW, W };
-        R = search_core(c, L, Vrow, Vcol, start, goal, order_cap, gclosed + (size_t)scene * (N >> 5), pinfo + (size_t)scene * N,
-                        orders ? orders + (size_t)scene * order_cap : nullptr, path, lane
-#ifdef DMPP_DEBUG_SEARCH
-                        , dbg_t, dbg_c
-#endif
-                        );
-    }
-#ifdef DMPP_DEBUG_SEARCH
-    if (lane == 0) publish_debug(path, c.max_path, dbg_t, dbg_c, t_setup, clock64() - t_begin);
-#endif
-    (void)t_setup;
-    if (lane == 0) {
-        cost_out[scene] = (int32_t)min((clock64() - t_begin) >> kOrderShift, (long long)(kOrderClasses - 1));
-        publish_search(gout[scene], R, start, goal);
-    }
-}
-
 // pp_get_grid: one scene's occupancy grid as bytes, produced by the SAME footprint code the search uses (so the tests see
 // what the search sees): the workgroup builds the sparse views and expands the row-major one; the column-major one is
-// checked against it cell by cell (mismatches counted in bad[0]).  bad[1] = 1 when the scene does not fit the LDS given.
+// checked against it cell by cell (mismatches counted in bad[0]).  A scene that does not fit the LDS given is written span
+// by span instead (bad[1] = 1: no cross-check of the two views then).
 template <int K>
 __global__ void __launch_bounds__(kSearchBlock)
 k_export_grid(PlannerConfig c, int scene, int budget, const SceneIn* __restrict__ in, const ObPoint* __restrict__ obs_now,
@@ -1112,8 +1073,18 @@ k_export_grid(PlannerConfig c, int scene, int budget, const SceneIn* __restrict_
         vr.data = (DMPP_LDS uint32_t*)(p + used); vc.data = vr.data + budget;
         vr.LW = WW; vr.NL = H; vc.LW = HW; vc.NL = W;
     }
-    const int need = build_sparse_views<K>(c, si, obs_now + si.obs_off, si.obs_n, vr, vc, budget, s_wave);
-    if (need > budget) { if (tid == 0) bad[1] = 1; return; }
+    const ObPoint* obs = obs_now + si.obs_off;
+    const int need = build_sparse_views<K>(c, si, obs, si.obs_n, vr, vc, budget, s_wave);
+    if (need > budget) {
+        if (tid == 0) bad[1] = 1;
+        for (int cell = tid; cell < W * H; cell += kSearchBlock) out[cell] = 0;
+        __threadfence();
+        __syncthreads();
+        for_each_span(c, si, obs, si.obs_n, [&](bool colhalf, int l, int a, int b) {
+            if (!colhalf) for (int x = a; x <= b; x++) out[l * W + x] = 1;
+        });
+        return;
+    }
     int mism = 0;
     for (int cell = tid; cell < W * H; cell += kSearchBlock) {
         const int x = cell % W, y = cell / W;

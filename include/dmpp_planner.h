@@ -46,8 +46,7 @@ typedef struct PlannerCaps {
 } PlannerCaps;
 
 /* kernels of one tick, in launch order; index into pp_get_kernel_ms */
-enum { PP_K_OBSTACLES = 0, PP_K_DECISION, PP_K_PLANNING, PP_K_RASTERISE /* unused: the search rasterises for itself */, PP_K_SEARCH, PP_K_SCORE,
-       PP_K_FALLBACK /* k_rasterise + k_search_gbm for the scenes k_search_lds hands on */, PP_K_COUNT };
+enum { PP_K_OBSTACLES = 0, PP_K_DECISION, PP_K_PLANNING, PP_K_SEARCH, PP_K_SCORE, PP_K_COUNT };
 /* device buffers addressable through pp_device_ptr (for RCCL scatter/gather by the caller) */
 enum { PP_BUF_SCENE_IN = 0, PP_BUF_LANE_POOL, PP_BUF_REF_POOL, PP_BUF_OBS_POOL, PP_BUF_MOT_POOL, PP_BUF_STATE,
        PP_BUF_PLAN_OUT, PP_BUF_GRID_OUT, PP_BUF_GRID, PP_BUF_PATH, PP_BUF_ORDER, PP_BUF_LANE_ATTR, PP_BUF_COUNT };
@@ -166,10 +165,11 @@ void* pp_stream(pp_handle h);       /* hipStream_t; ordered after the ticks only
  * 2 SceneIn, 3 SceneState, 4 PlanOut, 5 GridOut, 6 ObPoint, 7 ObMotion, 8 Path_Obs, 9 LocationOut,
  * 10 DecisionOutPod, 11 LaneView, 12 PlanningOut, 13 PlanningStatus, 14 AimPoint */
 size_t pp_sizeof(int which);
-/* Host-side launch geometry, callable without a GPU (tests): rows per band of the rasteriser for a grid of grid_h rows
- * and a batch of n_scenes (128 for large batches, narrower - always a multiple of 32 - when the batch does not fill
- * the chip). */
-int   pp_raster_band_rows(int grid_h, int n_scenes);
+/* The search keeps a scene's obstacle bitmaps sparse in LDS; a launch gives every scene `lds_budget_words` words per view
+ * (sized from what the densest scene of an earlier tick needed) and a scene that needs more is searched on dense bitmaps
+ * in HBM instead.  After a tick: the budget of that tick, the words the densest scene seen so far needed, and how many
+ * scenes of the last tick took the dense path.  Any pointer may be NULL. */
+int   pp_get_search_info(pp_handle h, int32_t* lds_budget_words, int32_t* need_words, int32_t* dense_scenes);
 /* After filling the input buffers through pp_device_ptr (an RCCL scatter straight into them): declares what is resident -
  * scenes, the used part of each pool, whether the motion pool / the lane attribute pool were filled - and checks every
  * scene's slices against those pools, like pp_set_scenes does. */

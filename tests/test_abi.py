@@ -81,17 +81,3 @@ def test_argument_checks_without_gpu(dm):
     assert b"null" in lib.pp_last_error() or b"config" in lib.pp_last_error()
     assert lib.pp_plan_tick(None) != 0 and lib.pp_sync(None) != 0
     assert lib.pp_destroy(None) == 0
-
-
-def test_raster_bands_are_whole_words(dm):
-    """k_rasterise packs 32 rows into a word of the column-major bitmap: whatever the batch size, a band must be a
-    multiple of 32 rows (a 96-row grid once got 48-row bands) and never taller than the grid."""
-    lib = dm.load_library()
-    lib.pp_raster_band_rows.restype = int
-    for gh in range(32, 4097, 32):
-        for n in (1, 2, 3, 5, 8, 17, 64, 127, 128, 255, 256, 1024, 8192):
-            b = lib.pp_raster_band_rows(gh, n)
-            assert b % 32 == 0 and 32 <= b <= min(gh, 128), (gh, n, b)
-    assert lib.pp_raster_band_rows(512, 1024) == 128 and lib.pp_raster_band_rows(512, 1) == 32
-    assert lib.pp_raster_band_rows(96, 1) == 96 and lib.pp_raster_band_rows(192, 1) == 32
-

@@ -813,9 +813,9 @@ def test_device_pointer_inputs_without_a_motion_pool(dm, oracle):
 @pytest.mark.parametrize("env,grid,n_obs", [({"DMPP_SEARCH_GBM": "1"}, 512, 64), ({"DMPP_LDS_BUDGET": "600"}, 512, 64),
                                             ({"DMPP_LDS_BUDGET": "64"}, 128, 24), ({"DMPP_SEARCH_GBM": "1"}, 2048, 64)])
 def test_search_fallback_paths(dm, oracle, env, grid, n_obs):
-    """The dense-bitmap search (k_rasterise -> HBM -> k_search_gbm) that takes the scenes whose obstacle words do not fit the
-    LDS budget of a launch: forced for every scene (DMPP_SEARCH_GBM), and with a budget so small that only some scenes fit
-    (DMPP_LDS_BUDGET: both kernels work on the same batch).  Same results as the oracle either way."""
+    """The dense form of the search's bitmaps (written to HBM by the scene's own workgroup) that takes the scenes whose obstacle
+    words do not fit the LDS budget of a launch: forced for every scene (DMPP_SEARCH_GBM), and with a budget so small that
+    only some scenes fit (DMPP_LDS_BUDGET: both forms in one launch).  Same results as the oracle either way."""
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -830,12 +830,10 @@ def test_search_fallback_paths(dm, oracle, env, grid, n_obs):
                              mutate=lambda sc_, t: move_ego(sc_, 4) if t else None)
         for t, r in enumerate(res):
             _assert_tick(r, f"{env} tick {t}")
-        kms = None
-        pl.set_profile(True)
-        pl.reset_kernel_ms()
-        pl.tick(sync=True)
-        kms = pl.kernel_ms()
-        assert kms["k_search_fallback"][1] == 1           # the fallback launches ran (and did real work in these cases)
+        budget, need, dense = pl.search_info()
+        assert dense > 0 and (dense == n or "DMPP_LDS_BUDGET" in env), (budget, need, dense)      # the dense path really ran
+        if "DMPP_LDS_BUDGET" in env:
+            assert 0 < dense < n and budget == int(env["DMPP_LDS_BUDGET"])
         if grid < 2048:
             for s_ in (0, 1, 5):
                 st1 = sc["state"].copy()
@@ -858,6 +856,7 @@ def test_lds_budget_adapts(dm, oracle):
     cfg = dm.default_config(256)
     n = 64
     pl = dm.Planner(cfg, max_scenes=n, max_obs_total=n * 200)
+    seen = []
     for n_obs, seed in ((6, 100), (200, 200), (6, 300)):
         sc = dm.gen_scenes(cfg, seed, n, n_obs, junction_every=0)
         st_o = sc["state"].copy()
@@ -868,3 +867,8 @@ def test_lds_budget_adapts(dm, oracle):
             plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st_o, n_threads=8, want_grid=True)
             bad = compare(pl.get_grid_out(), gout_o, "grid") + compare(pl.get_state(), st_o, "state")
             assert not bad, f"{n_obs} obstacles, tick {t}\n" + "\n".join(bad[:10])
+            seen.append(pl.search_info())
+    budgets = [b for b, _, _ in seen]
+    assert max(budgets[5:10]) > 2 * budgets[4], seen       # the budget grew with the dense scenes ...
+    assert seen[9][2] == 0, seen                           # ... until they all fit again
+    assert budgets[14] < max(budgets[5:10]), seen          # ... and shrank when they left

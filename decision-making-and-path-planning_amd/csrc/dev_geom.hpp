@@ -167,17 +167,76 @@ __device__ __forceinline__ GlobalPoint2D mean_point(const PlannerConfig& c, cons
     return o;
 }
 
-// Cumulative arc length of a polyline, executed by one full wave: segment lengths in
-// parallel, the running sum by lane 0 in index order.  cum must hold n doubles.
+
+// Order-dependent sums (arc lengths) are carried by ONE lane in index order, so their rounding equals a sequential host loop's;
+// what makes them fast is that the lane works on blocks of eight values: the eight LDS reads are issued together (one wait),
+// then eight dependent adds follow - ~10 cycles per element instead of an LDS round trip per element.
+
+// in place: v[i] <- v[lo] + ... + v[i] for i in [lo, hi), starting from `acc`; returns the total.  One lane.
+__device__ __forceinline__ double serial_prefix_inplace(double* v, int lo, int hi, double acc)
+{
+    int i = lo;
+    for (; i + 8 <= hi; i += 8) {
+        double a0 = v[i], a1 = v[i + 1], a2 = v[i + 2], a3 = v[i + 3], a4 = v[i + 4], a5 = v[i + 5], a6 = v[i + 6], a7 = v[i + 7];
+        a0 = acc + a0; a1 = a0 + a1; a2 = a1 + a2; a3 = a2 + a3; a4 = a3 + a4; a5 = a4 + a5; a6 = a5 + a6; a7 = a6 + a7;
+        v[i] = a0; v[i + 1] = a1; v[i + 2] = a2; v[i + 3] = a3; v[i + 4] = a4; v[i + 5] = a5; v[i + 6] = a6; v[i + 7] = a7;
+        acc = a7;
+    }
+    for (; i < hi; i++) { acc += v[i]; v[i] = acc; }
+    return acc;
+}
+// v[lo] + ... + v[hi-1] added to `acc` in index order.  One lane.
+__device__ __forceinline__ double serial_sum(const double* v, int lo, int hi, double acc)
+{
+    int i = lo;
+    for (; i + 8 <= hi; i += 8) {
+        const double a0 = v[i], a1 = v[i + 1], a2 = v[i + 2], a3 = v[i + 3], a4 = v[i + 4], a5 = v[i + 5], a6 = v[i + 6], a7 = v[i + 7];
+        acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+    }
+    for (; i < hi; i++) acc += v[i];
+    return acc;
+}
+// Adds v[0 .. cnt) to `sum` in index order and returns the first k with  sum - 4 > limit  (sum then holds the value at k),
+// or -1 with sum = the total.  One lane.  (The walk of SearchAimPoint, Planning.cpp:410-432.)
+__device__ __forceinline__ int serial_walk(const double* v, int cnt, double limit, double& sum)
+{
+    double acc = sum;
+    int i = 0;
+    for (; i + 8 <= cnt; i += 8) {
+        const double a0 = v[i], a1 = v[i + 1], a2 = v[i + 2], a3 = v[i + 3], a4 = v[i + 4], a5 = v[i + 5], a6 = v[i + 6], a7 = v[i + 7];
+        const double s0 = acc + a0, s1 = s0 + a1, s2 = s1 + a2, s3 = s2 + a3, s4 = s3 + a4, s5 = s4 + a5, s6 = s5 + a6, s7 = s6 + a7;
+        if (s7 - 4 > limit) {                              // the sums never decrease (lengths >= 0) but may be NaN: test each in order
+            const double ss[8] = { s0, s1, s2, s3, s4, s5, s6, s7 };
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (ss[k] - 4 > limit) { sum = ss[k]; return i + k; }
+        }
+        if (!(s7 - 4 <= limit)) {                          // a NaN among them: fall back to the one-by-one test for this block
+            const double ss[8] = { s0, s1, s2, s3, s4, s5, s6, s7 };
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (ss[k] - 4 > limit) { sum = ss[k]; return i + k; }
+        }
+        acc = s7;
+    }
+    for (; i < cnt; i++) { acc += v[i]; if (acc - 4 > limit) { sum = acc; return i; } }
+    sum = acc;
+    return -1;
+}
+
+// Cumulative arc length of a polyline, executed by one full wave: cum[0] = 0, cum[i] = cum[i-1] + |P[i] - P[i-1]|, the
+// additions in index order.  Segment lengths in parallel, the running sum by lane 0 (serial_prefix_inplace).
+// cum must hold n doubles.
 __device__ __forceinline__ void wave_cumlen(const GlobalPoint2D* path, int n, double* cum, int lane)
 {
     for (int i = 1 + lane; i < n; i += DMPP_WAVE) cum[i] = CalcDistance(path[i], path[i - 1]);
     wave_sync();
-    if (lane == 0 && n > 0) {
-        double acc = 0; cum[0] = 0;
-        for (int i = 1; i < n; i++) { acc += cum[i]; cum[i] = acc; }
-    }
+    if (lane == 0 && n > 0) { cum[0] = 0; serial_prefix_inplace(cum, 1, n, 0.0); }
     wave_sync();
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src)       // src must be wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
 }
 
 struct SoResult {
@@ -201,7 +260,17 @@ __device__ __forceinline__ SoResult wave_search_obstacle(const PlannerConfig& c,
     for (int j = lane; j < m; j += DMPP_WAVE) {
         const double ox = obs[j].x, oy = obs[j].y;
         double best = __builtin_inf(); int bi = 0;
-        for (int i = 0; i < n; i++) {
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {                         // four points per round: the (broadcast) reads are issued together
+            const GlobalPoint2D p0 = path[i], p1 = path[i + 1], p2 = path[i + 2], p3 = path[i + 3];
+            const double a0 = ox - p0.x, b0 = oy - p0.y, a1 = ox - p1.x, b1 = oy - p1.y, a2 = ox - p2.x, b2 = oy - p2.y, a3 = ox - p3.x, b3 = oy - p3.y;
+            const double e0 = a0 * a0 + b0 * b0, e1 = a1 * a1 + b1 * b1, e2 = a2 * a2 + b2 * b2, e3 = a3 * a3 + b3 * b3;
+            if (e0 < best) { best = e0; bi = i; }
+            if (e1 < best) { best = e1; bi = i + 1; }
+            if (e2 < best) { best = e2; bi = i + 2; }
+            if (e3 < best) { best = e3; bi = i + 3; }
+        }
+        for (; i < n; i++) {
             double dx = ox - path[i].x, dy = oy - path[i].y;
             double d2 = dx * dx + dy * dy;
             if (d2 < best) { best = d2; bi = i; }
@@ -229,6 +298,83 @@ __device__ __forceinline__ SoResult wave_search_obstacle(const PlannerConfig& c,
         if (take) { best_lng = o_lng; best_lat = o_lat; best_j = o_j; best_id = o_id; }
     }
     if (best_j != 0x7fffffff) { r.flag = 1; r.dis_lat = best_lat; r.dis_lng = best_lng; r.path_id = best_id; r.ob_index = best_j; }
+    return r;
+}
+
+// CShare::SearchObstacle for one polyline by a TEAM of TW waves of a 256-thread block (TW = 4: the whole block on one
+// polyline; TW = 2: two polylines side by side).  The team's first wave sums the arc lengths while every wave of the team
+// scans its share [n*k/TW, n*(k+1)/TW) of the points for all obstacles; the shares are merged per obstacle in point order
+// with the strict < of the sequential loop (so the first minimum wins), and the first wave finishes as wave_search_obstacle
+// does.  EVERY thread of the block must call it (block-wide barriers), with the same m; a team without a job passes
+// active = false.  part_d2 / part_bi: 256 entries each.  The result is valid in the team's first wave.
+template <int TW>
+__device__ __forceinline__ SoResult team_search_obstacle(const PlannerConfig& c, const GlobalPoint2D* path, int n, double* s,
+                                                         const ObPoint* obs, int m, double lat_lo, double lat_hi, bool active,
+                                                         double* part_d2, int* part_bi)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rank = wave % TW;
+    const bool leader = rank == 0;
+    SoResult r;
+    r.flag = 0; r.path_id = 0; r.ob_index = -1; r.dis_lat = c.NO_OBSTACLE_DIS; r.dis_lng = c.NO_OBSTACLE_DIS;
+    const bool run = active && n >= 2 && m >= 1;
+    if (run && leader) wave_cumlen(path, n, s, lane);
+    const int q0 = run ? (int)((long long)n * rank / TW) : 0, q1 = run ? (int)((long long)n * (rank + 1) / TW) : 0;
+    double best_lng = __builtin_inf(), best_lat = 0;
+    int best_j = 0x7fffffff, best_id = 0;
+    for (int j0 = 0; j0 < m; j0 += DMPP_WAVE) {
+        const int j = j0 + lane;
+        double best = __builtin_inf(); int bi = 0;
+        double ox = 0, oy = 0;
+        if (run && j < m) {
+            ox = obs[j].x; oy = obs[j].y;
+            int i = q0;
+            for (; i + 4 <= q1; i += 4) {                    // four points per round: the (broadcast) reads are issued together
+                const GlobalPoint2D p0 = path[i], p1 = path[i + 1], p2 = path[i + 2], p3 = path[i + 3];
+                const double a0 = ox - p0.x, b0 = oy - p0.y, a1 = ox - p1.x, b1 = oy - p1.y, a2 = ox - p2.x, b2 = oy - p2.y, a3 = ox - p3.x, b3 = oy - p3.y;
+                const double e0 = a0 * a0 + b0 * b0, e1 = a1 * a1 + b1 * b1, e2 = a2 * a2 + b2 * b2, e3 = a3 * a3 + b3 * b3;
+                if (e0 < best) { best = e0; bi = i; }
+                if (e1 < best) { best = e1; bi = i + 1; }
+                if (e2 < best) { best = e2; bi = i + 2; }
+                if (e3 < best) { best = e3; bi = i + 3; }
+            }
+            for (; i < q1; i++) {
+                const double dx = ox - path[i].x, dy = oy - path[i].y, d2 = dx * dx + dy * dy;
+                if (d2 < best) { best = d2; bi = i; }
+            }
+        }
+        part_d2[tid] = best; part_bi[tid] = bi;
+        __syncthreads();
+        if (run && leader && j < m) {
+            best = __builtin_inf(); bi = 0;
+#pragma unroll
+            for (int k = 0; k < TW; k++) { const double d = part_d2[tid + k * DMPP_WAVE]; if (d < best) { best = d; bi = part_bi[tid + k * DMPP_WAVE]; } }
+            const int idx = (bi == n - 1) ? n - 2 : bi;
+            const GlobalPoint2D a = path[idx], b = path[idx + 1], o = { ox, oy };
+            bool ok = true;
+            if (bi == 0) { double t = (ox - a.x) * (b.x - a.x) + (oy - a.y) * (b.y - a.y); if (t < 0) ok = false; }
+            if (bi == n - 1) { double t = (ox - b.x) * (b.x - a.x) + (oy - b.y) * (b.y - a.y); if (t > 0) ok = false; }
+            if (ok) {
+                const double lat = GetLatDis(c, o, a, b);
+                if (!(lat < lat_lo || lat > lat_hi)) {
+                    const double lng = s[bi];
+                    if (best_j == 0x7fffffff || lng < best_lng) { best_lng = lng; best_lat = lat; best_j = j; best_id = bi; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (run && leader) {
+        // reduce on (lng, j): the sequential loop keeps the first obstacle with the smallest lng
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            double o_lng = shfl_xor_f64(best_lng, sft);
+            double o_lat = shfl_xor_f64(best_lat, sft);
+            int o_j = __shfl_xor(best_j, sft, 64), o_id = __shfl_xor(best_id, sft, 64);
+            bool take = (o_j != 0x7fffffff) && (best_j == 0x7fffffff || o_lng < best_lng || (o_lng == best_lng && o_j < best_j));
+            if (take) { best_lng = o_lng; best_lat = o_lat; best_j = o_j; best_id = o_id; }
+        }
+        if (best_j != 0x7fffffff) { r.flag = 1; r.dis_lat = best_lat; r.dis_lng = best_lng; r.path_id = best_id; r.ob_index = best_j; }
+    }
     return r;
 }
 

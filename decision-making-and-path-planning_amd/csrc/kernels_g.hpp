@@ -43,13 +43,14 @@ k_order(int n_scenes, const int32_t* __restrict__ cost, int32_t* __restrict__ pe
 // G3.  256 threads = 4 waves per scene; wave w scores candidates w, w+4, ...
 // NW waves per scene score the candidates NW at a time: 4 for batches (four scenes per CU), 16 for the few scenes of a
 // latency-bound tick (17 candidates in 2 rounds instead of 5).
+constexpr int kMaxRelObs = 128;      // culled obstacle list kept in LDS; a scene with more candidates near its paths reads the whole list from HBM
 template <int NW>
 struct ScoreShared {
     GlobalPoint2D cand[NW][DMPP_PATH_POINTS];
     double seg[NW][DMPP_PATH_POINTS];        // |P_i - P_{i+1}| of the wave's current candidate
     GlobalPoint2D pts[DMPP_PATH_POINTS];     // grid-path prefix in metres (lookahead_cells+1 <= 200)
     double cum[DMPP_PATH_POINTS];
-    double rx[kMaxObsLds], ry[kMaxObsLds], rr[kMaxObsLds], rt2[kMaxObsLds];   // obstacles that can matter: x, y, radius, cutoff^2
+    double rx[kMaxRelObs], ry[kMaxRelObs], rr[kMaxRelObs], rt2[kMaxRelObs];   // obstacles that can matter: x, y, radius, cutoff^2
     double bx0[DMPP_MAX_LATTICE], bx1[DMPP_MAX_LATTICE], by0[DMPP_MAX_LATTICE], by1[DMPP_MAX_LATTICE];
     double cost[DMPP_MAX_LATTICE];
     int best, n_rel;
@@ -143,18 +144,18 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
         const double px0 = si.grid_origin.x + ((double)(pc0 % W) + 0.5) * c.cell, py0 = si.grid_origin.y + ((double)(pc0 / W) + 0.5) * c.cell;
         X0 = fmin(X0, px0 - ext); X1 = fmax(X1, px0 + ext); Y0 = fmin(Y0, py0 - ext); Y1 = fmax(Y1, py0 + ext);
     }
-    const bool culled = m <= kMaxObsLds;          // longer lists are read from HBM without culling
-    if (culled) {
-        for (int j = tid; j < m; j += kThreads) {
-            const ObPoint o = gobs[j];
-            const double thr = (double)o.radius + half_w + c.d_safe;
-            if (o.x >= X0 - thr && o.x <= X1 + thr && o.y >= Y0 - thr && o.y <= Y1 + thr) {
-                const int q = atomicAdd(&sh.n_rel, 1);           // order is irrelevant: only a minimum is taken
-                sh.rx[q] = o.x; sh.ry[q] = o.y; sh.rr[q] = (double)o.radius; sh.rt2[q] = thr * thr;
-            }
+    // the obstacles near the candidates, collected in LDS (kMaxRelObs of them); when more qualify, the scoring loop reads the
+    // whole list from HBM instead (the same minimum over the same thresholds either way)
+    for (int j = tid; j < m; j += kThreads) {
+        const ObPoint o = gobs[j];
+        const double thr = (double)o.radius + half_w + c.d_safe;
+        if (o.x >= X0 - thr && o.x <= X1 + thr && o.y >= Y0 - thr && o.y <= Y1 + thr) {
+            const int q = atomicAdd(&sh.n_rel, 1);           // order is irrelevant: only a minimum is taken
+            if (q < kMaxRelObs) { sh.rx[q] = o.x; sh.ry[q] = o.y; sh.rr[q] = (double)o.radius; sh.rt2[q] = thr * thr; }
         }
     }
     __syncthreads();
+    const bool culled = sh.n_rel <= kMaxRelObs;
     const int n_rel = culled ? sh.n_rel : m;
     GlobalPoint2D* cand = sh.cand[wave];
     double* seg = sh.seg[wave];

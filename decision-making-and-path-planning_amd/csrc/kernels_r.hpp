@@ -17,6 +17,14 @@
 namespace dmpp {
 
 constexpr int kBlock = 256;
+
+// Debug build (make debug): cycle stamps of the phases of k_decision / k_planning, written by thread 0 into the unused tail of
+// the scene's decision-refpath slots (tools/dbg_front.py reads them with pp_get_refpath).
+#ifdef DMPP_DEBUG_SEARCH
+#define FRONT_MARK(slot) { if (threadIdx.x == 0) dbg_stamp[slot] = (double)(clock64() - dbg_t0); }
+#else
+#define FRONT_MARK(slot)
+#endif
 constexpr int kMaxObsLds = 512;   // obstacle records staged in LDS; longer lists are read from HBM
 
 // ---------------------------------------------------------------------------------------
@@ -83,7 +91,7 @@ __device__ inline double d_CalculateRadius(const GlobalPoint2D* last, int near_i
 // Block-wide arc-length walk shared by every branch of SearchAimPoint (Planning.cpp:410-432,
 // 448-469,478-499,507-538): accumulate |P[i+1]-P[i]| for i = i0 .. iend-1 in index order and
 // stop at the first i with sum - 4 > faraim.  Segment lengths are computed 256 at a time in
-// parallel; thread 0 adds them sequentially so the rounding equals the scalar loop.
+// parallel; thread 0 adds them in order, eight per block of reads (serial_walk), so the rounding equals the scalar loop.
 // base/stride: point i is (base[i*stride], base[i*stride+1]).  Returns the index or -1.
 __device__ inline int block_aim_walk(const double* base, int stride, int i0, int iend, double faraim,
                                      double* seg, int* sh_found, double* sh_sum)
@@ -102,11 +110,8 @@ __device__ inline int block_aim_walk(const double* base, int stride, int i0, int
         __syncthreads();
         if (tid == 0) {
             double sum = *sh_sum;
-            int cnt = iend - c0 < kBlock ? iend - c0 : kBlock;
-            for (int k = 0; k < cnt; k++) {
-                sum += seg[k];
-                if (sum - 4 > faraim) { *sh_found = c0 + k; break; }
-            }
+            const int k = serial_walk(seg, iend - c0 < kBlock ? iend - c0 : kBlock, faraim, sum);
+            if (k >= 0) *sh_found = c0 + k;
             *sh_sum = sum;
         }
         __syncthreads();
@@ -116,20 +121,28 @@ __device__ inline int block_aim_walk(const double* base, int stride, int i0, int
 }
 
 // ---------------------------------------------------------------------------------------
-struct DecShared {
-    GlobalPoint2D F[DMPP_FRONT_POINTS], R[DMPP_REAR_POINTS], LF[DMPP_FRONT_POINTS], LR[DMPP_REAR_POINTS],
-                  RF[DMPP_FRONT_POINTS], RR[DMPP_REAR_POINTS];
-    GlobalPoint2D tmp[4][DMPP_FRONT_POINTS];      // one offset candidate per wave
-    GlobalPoint2D ref[DMPP_MAX_REFPATH];          // junction front path
-    double s0[DMPP_MAX_REFPATH];                  // arc-length scratch of wave 0 (also the junction path, up to 512 points)
-    double s123[3][DMPP_FRONT_POINTS];            // ... of waves 1..3 (corridors and sweep candidates: <= 120 points)
-    ObPoint obs[kMaxObsLds];
+struct DecShared {                                 // 19 KB: small enough to sit beside the searching workgroups of a CU
+    union {
+        struct {                                    // road segment: the six corridors, two offset candidates, scratch
+            GlobalPoint2D F[DMPP_FRONT_POINTS], R[DMPP_REAR_POINTS], LF[DMPP_FRONT_POINTS], LR[DMPP_REAR_POINTS],
+                          RF[DMPP_FRONT_POINTS], RR[DMPP_REAR_POINTS];
+            GlobalPoint2D tmp[2][DMPP_FRONT_POINTS];    // one offset candidate per team of two waves
+            double s0[DMPP_FRONT_POINTS], s1[DMPP_FRONT_POINTS];   // arc-length scratch of the two teams
+            double seg[kBlock]; unsigned char sa[kBlock];          // remaining lane-change length: segment lengths + attributes
+        } road;
+        struct {                                    // (pre-)junction: the front path (<= 512 points) and its arc lengths
+            GlobalPoint2D ref[DMPP_MAX_REFPATH];
+            double s0[DMPP_MAX_REFPATH];
+        } junc;
+    } u;
+    double part_d2[kBlock]; int part_bi[kBlock];      // team_search_obstacle
     SoResult around[6];
     double sweep_lng[2 * DMPP_MAX_SWEEP];
     int n[6];
     int n_ref, do_sweep, n_cand;
     int rem_go, rem_flags;                        // remaining lane-change length tests (lane-change rule tree)
 };
+
 
 __device__ inline int dev_load_front(const PlannerConfig& c, const GlobalPoint3D* lane, int IdSum, int Id, GlobalPoint2D* out)
 {   // Decision.cpp:581-587
@@ -351,18 +364,18 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
     __builtin_amdgcn_s_setprio(3);             // front chain: ahead of the searching waves on the same SIMD
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef DMPP_DEBUG_SEARCH
+    const long long dbg_t0 = clock64();
+    double* dbg_stamp = reinterpret_cast<double*>(dec_ref + (size_t)blockIdx.x * DMPP_MAX_REFPATH + 480);
+#endif
+    const int tid = threadIdx.x, wave = tid >> 6;
     const SceneIn& si = in[scene];
     SceneState& st = state[scene];
     PlanOut& po = plan[scene];
     const LocationOut& loc = si.loc;
     const int m = si.obs_n;
-    const ObPoint* gobs = obs_now + si.obs_off;
-    const ObPoint* obs = gobs;
-    if (m <= kMaxObsLds) {
-        for (int j = tid; j < m; j += kBlock) sh.obs[j] = gobs[j];
-        obs = sh.obs;
-    }
+    const ObPoint* obs = obs_now + si.obs_off;       // read where they are: every lane needs its obstacle once per query
+    FRONT_MARK(0)
     const double hv = 0.5 * c.Vehicle_Width;
     GlobalPoint2D* out_ref = dec_ref + (size_t)scene * DMPP_MAX_REFPATH;
     const int pos = loc.pos;
@@ -373,8 +386,8 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         const int Id_Cur = loc.id[clampi(LaneNum_Cur - 1, 0, DMPP_LANESUM - 1)];
         const double W = si.lanes.lane_width;
         const GlobalPoint3D* cur = lane_pool + si.lanes.cur_off;
-        int nF = dev_load_front(c, cur, si.lanes.cur_n, Id_Cur, sh.F);
-        int nR = dev_load_rear(c, cur, si.lanes.cur_n, Id_Cur, sh.R);
+        int nF = dev_load_front(c, cur, si.lanes.cur_n, Id_Cur, sh.u.road.F);
+        int nR = dev_load_rear(c, cur, si.lanes.cur_n, Id_Cur, sh.u.road.R);
         int nLF = 0, nLR = 0, nRF = 0, nRR = 0;
         int synth_left = 0, synth_right = 0;
         if (LaneChg == 1 || LaneChg == 3) {
@@ -382,8 +395,8 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
                 int Id_L = loc.id[clampi(LaneNum_Cur - 2, 0, DMPP_LANESUM - 1)], Sum_L = si.lanes.left_n;
                 if (Id_L > 0 && Id_L < Sum_L) {
                     const GlobalPoint3D* left = lane_pool + si.lanes.left_off;
-                    nLF = dev_load_front(c, left, Sum_L, Id_L, sh.LF);
-                    nLR = dev_load_rear(c, left, Sum_L, Id_L, sh.LR);
+                    nLF = dev_load_front(c, left, Sum_L, Id_L, sh.u.road.LF);
+                    nLR = dev_load_rear(c, left, Sum_L, Id_L, sh.u.road.LR);
                 }
             } else synth_left = 1;
         }
@@ -392,34 +405,40 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
                 int Id_Rt = loc.id[clampi(LaneNum_Cur, 0, DMPP_LANESUM - 1)], Sum_Rt = si.lanes.right_n;
                 if (Id_Rt > 0 && Id_Rt < Sum_Rt) {
                     const GlobalPoint3D* right = lane_pool + si.lanes.right_off;
-                    nRF = dev_load_front(c, right, Sum_Rt, Id_Rt, sh.RF);
-                    nRR = dev_load_rear(c, right, Sum_Rt, Id_Rt, sh.RR);
+                    nRF = dev_load_front(c, right, Sum_Rt, Id_Rt, sh.u.road.RF);
+                    nRR = dev_load_rear(c, right, Sum_Rt, Id_Rt, sh.u.road.RR);
                 }
             } else synth_right = 1;
         }
         __syncthreads();
         if (synth_left) {          // Decision.cpp:629-631
-            for (int i = tid; i < nF; i += kBlock) sh.LF[i] = offset_point(c, sh.F, nF, i, -1 * W);
-            for (int i = tid; i < nR; i += kBlock) sh.LR[i] = offset_point(c, sh.R, nR, i, -1 * W);
+            for (int i = tid; i < nF; i += kBlock) sh.u.road.LF[i] = offset_point(c, sh.u.road.F, nF, i, -1 * W);
+            for (int i = tid; i < nR; i += kBlock) sh.u.road.LR[i] = offset_point(c, sh.u.road.R, nR, i, -1 * W);
             nLF = nF; nLR = nR;
         }
         if (synth_right) {         // Decision.cpp:667-669
-            for (int i = tid; i < nF; i += kBlock) sh.RF[i] = offset_point(c, sh.F, nF, i, W);
-            for (int i = tid; i < nR; i += kBlock) sh.RR[i] = offset_point(c, sh.R, nR, i, W);
+            for (int i = tid; i < nF; i += kBlock) sh.u.road.RF[i] = offset_point(c, sh.u.road.F, nF, i, W);
+            for (int i = tid; i < nR; i += kBlock) sh.u.road.RR[i] = offset_point(c, sh.u.road.R, nR, i, W);
             nRF = nF; nRR = nR;
         }
         __syncthreads();
+        FRONT_MARK(1)
         // ---- AroundObstacle, Decision.cpp:759-881: six corridor queries over four waves ----
-        const GlobalPoint2D* P[6] = { sh.F, sh.R, sh.LF, sh.LR, sh.RF, sh.RR };
+        const GlobalPoint2D* P[6] = { sh.u.road.F, sh.u.road.R, sh.u.road.LF, sh.u.road.LR, sh.u.road.RF, sh.u.road.RR };
         const int N[6] = { nF, nR, nLF, nLR, nRF, nRR };
         const double LO[6] = { -hv, -hv, -hv, -hv, -0.5 * W, -0.5 * W };
         const double HI[6] = { hv, hv, 0.5 * W, 0.5 * W, hv, hv };
-        for (int t = wave; t < 6; t += 4) {
-            SoResult r = wave_search_obstacle(c, P[t], N[t], wave == 0 ? sh.s0 : sh.s123[wave - 1], obs, m, LO[t], HI[t], lane);
-            if (lane == 0) { sh.around[t] = r; sh.n[t] = N[t]; }
+        {   // two teams of two waves, three rounds: corridor t = 2 * round + team
+            const int team = wave >> 1;
+            for (int rd = 0; rd < 3; rd++) {
+                const int t = 2 * rd + team;
+                const SoResult r = team_search_obstacle<2>(c, P[t], N[t], team == 0 ? sh.u.road.s0 : sh.u.road.s1, obs, m, LO[t], HI[t], true, sh.part_d2, sh.part_bi);
+                if ((tid & 127) == 0) { sh.around[t] = r; sh.n[t] = N[t]; }
+            }
         }
         __syncthreads();
         if (tid < 6) store_path_obs(&po.around[tid], sh.around[tid], obs, sh.n[tid] != 0);
+        FRONT_MARK(2)
         // ---- BehaviorDecision, no-lane-change map: Decision.cpp:920-1010 ----
         // (an empty front path leaves dis_lng = 0 from the memset at Decision.cpp:794)
         const double F_lng = (nF != 0) ? sh.around[0].dis_lng : 0.0;
@@ -429,17 +448,20 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         const int do_sweep = (LaneChg == 0) && (F_lng < 15) && (st.obsavoid_time + 1 > 2);
         if (do_sweep) {
             // the candidates of both sides are independent: evaluate all, pick the first accepted
-            for (int t = wave; t < 2 * n_cand; t += 4) {
-                const int side = t / n_cand, i = t - side * n_cand;
+            const int team = wave >> 1;                                        // two teams of two waves, one candidate each per round
+            for (int t0 = 0; t0 < 2 * n_cand; t0 += 2) {
+                const int t = t0 + team;
+                const bool act = t < 2 * n_cand;
+                const int side = act ? t / n_cand : 0, i = act ? t - side * n_cand : 0;
                 const double off = (side == 0 ? -0.3 : 0.3) * (double)i;      // Decision.cpp:942,961
-                for (int k = lane; k < nF; k += DMPP_WAVE) sh.tmp[wave][k] = offset_point(c, sh.F, nF, k, off);
-                wave_sync();
-                SoResult r = wave_search_obstacle(c, sh.tmp[wave], nF, wave == 0 ? sh.s0 : sh.s123[wave - 1], obs, m, -hv, hv, lane);
-                if (lane == 0) sh.sweep_lng[side * DMPP_MAX_SWEEP + i] = r.dis_lng;
-                wave_sync();
+                if (act) for (int k = tid & 127; k < nF; k += 128) sh.u.road.tmp[team][k] = offset_point(c, sh.u.road.F, nF, k, off);
+                __syncthreads();
+                const SoResult r = team_search_obstacle<2>(c, sh.u.road.tmp[team], nF, team == 0 ? sh.u.road.s0 : sh.u.road.s1, obs, m, -hv, hv, act, sh.part_d2, sh.part_bi);
+                if (act && (tid & 127) == 0) sh.sweep_lng[side * DMPP_MAX_SWEEP + i] = r.dis_lng;
             }
         }
         __syncthreads();
+        FRONT_MARK(3)
         // ---- lane-change rule tree, part 1: the "remaining lane-change length" tests ----
         // Decision.cpp:1178-1187 (and :1212, 1316, 1344, 1459, 1477, 1506, 1523) walk the current lane from the ego point
         // while the next point's lanechg_attribute passes a predicate, summing segment lengths, and compare the sum with
@@ -449,8 +471,8 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         //   rem_flags bit0: A > 60, bit1: B > 10, bit2: B > 15, bit3: B > 50
         const bool run_tree = (LaneChg != 0) && c.lanechg_stage;
         if (run_tree) {
-            double* seg = reinterpret_cast<double*>(sh.ref);
-            unsigned char* sa = reinterpret_cast<unsigned char*>(seg + kBlock);
+            double* seg = sh.u.road.seg;
+            unsigned char* sa = sh.u.road.sa;
             const uint8_t* attr = attr_pool + si.lanes.cur_off;
             const int IdSum = si.lanes.cur_n;
             int base = max(Id_Cur, 0);
@@ -486,6 +508,7 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
                 base += kBlock;
             }
         }
+        FRONT_MARK(4)
         if (tid == 0) {
             // Nav_LaneChange, Decision.cpp:685-738 (+ CalcNaviLaneChgTimes :498-538)
             unsigned navi = 4, navi_times = 0;
@@ -564,7 +587,7 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         __syncthreads();
         {
             const int beh = sh.do_sweep;
-            const GlobalPoint2D* src = (beh == 2) ? sh.LF : (beh == 3) ? sh.RF : sh.F;
+            const GlobalPoint2D* src = (beh == 2) ? sh.u.road.LF : (beh == 3) ? sh.u.road.RF : sh.u.road.F;
             for (int i = tid; i < sh.n_ref; i += kBlock) out_ref[i] = src[i];
         }
     } else if (pos == 1 || pos == 2) {
@@ -576,21 +599,21 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
             int Id_Cur = max(loc.id[clampi(loc.lane_num - 1, 0, DMPP_LANESUM - 1)], 0);
             int n1 = max(si.lanes.cur_n - Id_Cur, 0); n1 = min(n1, DMPP_MAX_REFPATH);
             int n2 = min(max(si.ref_n, 0), DMPP_MAX_REFPATH - n1);
-            for (int k = tid; k < n1; k += kBlock) { sh.ref[k].x = cur[Id_Cur + k].x; sh.ref[k].y = cur[Id_Cur + k].y; }
-            for (int k = tid; k < n2; k += kBlock) sh.ref[n1 + k] = inter[k];
+            for (int k = tid; k < n1; k += kBlock) { sh.u.junc.ref[k].x = cur[Id_Cur + k].x; sh.u.junc.ref[k].y = cur[Id_Cur + k].y; }
+            for (int k = tid; k < n2; k += kBlock) sh.u.junc.ref[n1 + k] = inter[k];
             n = n1 + n2;
         } else {
             int Id_Inter = max(loc.id[clampi(loc.last_lanenum - 1, 0, DMPP_LANESUM - 1)], 0);
             int n1 = max(si.ref_n - Id_Inter, 0); n1 = min(n1, DMPP_MAX_REFPATH);
             int n2 = min(min(60, si.lanes.cur_n), DMPP_MAX_REFPATH - n1); n2 = max(n2, 0);
-            for (int k = tid; k < n1; k += kBlock) sh.ref[k] = inter[Id_Inter + k];
-            for (int k = tid; k < n2; k += kBlock) { sh.ref[n1 + k].x = cur[k].x; sh.ref[n1 + k].y = cur[k].y; }
+            for (int k = tid; k < n1; k += kBlock) sh.u.junc.ref[k] = inter[Id_Inter + k];
+            for (int k = tid; k < n2; k += kBlock) { sh.u.junc.ref[n1 + k].x = cur[k].x; sh.u.junc.ref[n1 + k].y = cur[k].y; }
             n = n1 + n2;
         }
         __syncthreads();
-        if (wave == 0) {
-            SoResult r = wave_search_obstacle(c, sh.ref, n, sh.s0, obs, m, -hv, hv, lane);
-            if (lane == 0) sh.around[0] = r;
+        {
+            const SoResult r = team_search_obstacle<4>(c, sh.u.junc.ref, n, sh.u.junc.s0, obs, m, -hv, hv, true, sh.part_d2, sh.part_bi);
+            if (tid == 0) sh.around[0] = r;
         }
         __syncthreads();
         if (tid < 6) {
@@ -606,13 +629,14 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
             po.sweep_side = 0; po.sweep_index = -1; po.navi_lanechg = 0; po.navi_lanechg_times = 0;
             sh.n_ref = n;
         }
-        for (int i = tid; i < n; i += kBlock) out_ref[i] = sh.ref[i];
+        for (int i = tid; i < n; i += kBlock) out_ref[i] = sh.u.junc.ref[i];
         __syncthreads();
     } else {
         if (tid < 6) { SoResult z; z.flag = 0; z.path_id = 0; z.ob_index = -1; z.dis_lat = 0; z.dis_lng = 0; store_path_obs(&po.around[tid], z, obs, false); }
         if (tid == 0) { sh.n_ref = 0; po.sweep_side = 0; po.sweep_index = -1; po.navi_lanechg = 0; po.navi_lanechg_times = 0; }
         __syncthreads();
     }
+    FRONT_MARK(5)
     if (tid == 0) {       // Decision.cpp:187-201
         DecisionOutPod d;
         d.velocity_expect = st.z_velocity_expect; d.behavior = st.z_behavior; d.target_roadnum = st.z_target_roadnum;
@@ -630,7 +654,7 @@ struct PlanShared {
     double dist[kBlock];           // also the 256-wide segment buffer of block_aim_walk
     double seg[DMPP_PATH_POINTS];
     double s[DMPP_PATH_POINTS + 8];
-    ObPoint obs[kMaxObsLds];
+    double part_d2[kBlock]; int part_bi[kBlock];      // team_search_obstacle
     AimPoint aim_far;
     SoResult so;
     double sh_sum;
@@ -647,6 +671,10 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
     __builtin_amdgcn_s_setprio(3);             // front chain: ahead of the searching waves on the same SIMD
+#ifdef DMPP_DEBUG_SEARCH
+    const long long dbg_t0 = clock64();
+    double* dbg_stamp = const_cast<double*>(reinterpret_cast<const double*>(dec_ref + (size_t)blockIdx.x * DMPP_MAX_REFPATH + 490));
+#endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const SceneIn& si = in[scene];
     SceneState& st = state[scene];
@@ -654,9 +682,7 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     const LocationOut& loc = si.loc;
     const int pos = loc.pos;
     const int m = si.obs_n;
-    const ObPoint* gobs = obs_now + si.obs_off;
-    const ObPoint* obs = gobs;
-    if (m <= kMaxObsLds) { for (int j = tid; j < m; j += kBlock) sh.obs[j] = gobs[j]; obs = sh.obs; }
+    const ObPoint* obs = obs_now + si.obs_off;
 
     // DecisionOut: published by k_decision into PlanOut.dec, or the caller's (decision stage off)
     DecisionOutPod dec;
@@ -757,6 +783,7 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     const AimPoint aim_far = sh.aim_far;
     if (near_follows_far) aim_near_new = aim_far;
 
+    FRONT_MARK(0)
     // ---- first tick: InitialPlanning, Planning.cpp:124-128,596-611 ----
     const int count = st.count;
     if (count == 0) {
@@ -767,6 +794,7 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     }
     __syncthreads();
 
+    FRONT_MARK(1)
     // ---- GetVhclLocalState, Planning.cpp:623-676 ----
     if (tid < DMPP_PATH_POINTS) {
         double dx = ego.x - sh.last[tid].x, dy = ego.y - sh.last[tid].y;
@@ -777,15 +805,24 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        double mind = 9999; int mid = clampi(st.path_near_id, 0, DMPP_PATH_POINTS - 1);
-        for (int i = 0; i < 200; i++) if (sh.dist[i] < mind) { mind = sh.dist[i]; mid = i; }   // first minimum
+    if (wave == 0) {
+        // first minimum of the 200 distances below 9999 (Planning.cpp:640-650: strict <, so ties keep the lower index; a NaN is
+        // never smaller): every lane over its four indices in order, then a (value, index) reduction over the wave
+        double mind = 9999; int mid = -1;
+        for (int k = 0; k < 4; k++) { const int i = lane + 64 * k; if (i < DMPP_PATH_POINTS && sh.dist[i] < mind) { mind = sh.dist[i]; mid = i; } }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const double o_d = shfl_xor_f64(mind, sft); const int o_i = __shfl_xor(mid, sft, 64);
+            if (o_i >= 0 && (mid < 0 || o_d < mind || (o_d == mind && o_i < mid))) { mind = o_d; mid = o_i; }
+        }
+        if (mid < 0) mid = clampi(st.path_near_id, 0, DMPP_PATH_POINTS - 1);      // nothing within 9999 m: the member keeps its value
         const int fid = mid + 8;
+        // remaining length: seg[fid] + ... + seg[198] in index order (Planning.cpp:668-671), one lane, eight reads per block
+      if (lane == 0) {
+        const double remain = serial_sum(sh.seg, min(fid, DMPP_PATH_POINTS - 1), DMPP_PATH_POINTS - 1, 0.0);
         const int index = (mid == 199) ? mid - 1 : mid;
         const GlobalPoint2D pt = sh.last[index], pt_next = sh.last[index + 1], vp = { ego.x, ego.y };
         const double lat = GetLatDis(c, vp, pt, pt_next);
-        double remain = 0;
-        for (int i = fid; i < 199; i++) remain += sh.seg[i];
         const double pt_dir = GetRoadAngle(c, pt, pt_next);
         const double dir_err = GetAngleErr(pt_dir, ego.dir);
         // ---- UpdatePlanJudge, Planning.cpp:797-832 ----
@@ -802,9 +839,11 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         sh.na = na;
         // CalculateRadius, Planning.cpp:1000-1019: runs on the OLD path (called at :199, path saved at :217)
         po.result.radius = d_CalculateRadius(sh.last, mid, fid);
+      }
     }
     __syncthreads();
 
+    FRONT_MARK(2)
     // ---- PathPlanning, Planning.cpp:845-877 (or reuse of the last path, :144-145) ----
     const int afresh = sh.afresh;
     if (afresh) {
@@ -824,15 +863,17 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     }
     __syncthreads();
 
+    FRONT_MARK(3)
     // ---- SearchObstacle on the remaining path, Planning.cpp:153-168 ----
     const int near_id = clampi(sh.near_id, 0, 200);
-    if (wave == 0) {
-        SoResult r = wave_search_obstacle(c, sh.road + near_id, DMPP_PATH_POINTS - near_id, sh.s, obs, m,
-                                          (double)(float)(-1.1), (double)(float)(1.1), lane);
-        if (lane == 0) sh.so = r;
+    {   // the whole block on the one polyline: four shares of the points
+        const SoResult r = team_search_obstacle<4>(c, sh.road + near_id, DMPP_PATH_POINTS - near_id, sh.s, obs, m,
+                                                   (double)(float)(-1.1), (double)(float)(1.1), true, sh.part_d2, sh.part_bi);
+        if (tid == 0) sh.so = r;
     }
     __syncthreads();
 
+    FRONT_MARK(4)
     // ---- SpeedPlanning + publication, Planning.cpp:171-223 ----
     if (tid == 0) {
         const SoResult r = sh.so;
@@ -872,6 +913,7 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
             po.result.pnts[k] = g;
         }
     }
+    FRONT_MARK(5)
 }
 
 }  // namespace dmpp

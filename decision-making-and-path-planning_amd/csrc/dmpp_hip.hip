@@ -85,7 +85,7 @@ struct pp_planner {
     // op scratch (stand-alone operators)
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
     // profiling
-    bool profile = false;
+    int profile = 0;             // 0 off, 1 every kernel of a tick between HIP events, 2 only the search kernel
     std::vector<EvPair> pending; std::vector<hipEvent_t> free_events;
     float k_ms[PP_K_COUNT] = {0}; int k_launches[PP_K_COUNT] = {0};
 };
@@ -135,12 +135,13 @@ int join_all(pp_planner* h)
 }
 
 struct Timed {
-    pp_planner* h; int k; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    pp_planner* h; int k; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on = false;
     Timed(pp_planner* h_, int k_, hipStream_t st_ = nullptr) : h(h_), k(k_), st(st_ ? st_ : h_->stream) {
-        if (h->profile) { a = get_event(h); b = get_event(h); if (a) (void)hipEventRecord(a, st); }
+        on = h->profile == 1 || (h->profile == 2 && k == PP_K_SEARCH);
+        if (on) { a = get_event(h); b = get_event(h); if (a) (void)hipEventRecord(a, st); }
     }
     ~Timed() {
-        if (h->profile && a && b) { (void)hipEventRecord(b, st); h->pending.push_back({a, b, k}); }
+        if (on && a && b) { (void)hipEventRecord(b, st); h->pending.push_back({a, b, k}); }
     }
 };
 
@@ -989,7 +990,7 @@ int pp_set_profile(pp_handle h, int on)
 {
     if (!h) return fail(PP_ERR_ARG, "null handle");
     int r = drain_events(h); if (r) return r;
-    h->profile = on != 0;
+    h->profile = on < 0 ? 0 : (on > 2 ? 1 : on);
     return PP_OK;
 }
 int pp_get_kernel_ms(pp_handle h, int k, float* ms_total, int* launches)

@@ -260,13 +260,16 @@ __device__ __forceinline__ bool exact_span(double ou, double org, double cell, d
 {
     if (dv2 > R2) return false;                            // du*du >= 0: no index can satisfy the predicate
     auto pred = [&](int i) { const double du = (org + ((double)i + 0.5) * cell) - ou; return du * du + dv2 <= R2; };
-    const double half = sqrt(R2 - dv2);
-    a = (int)ceil((ou - half - org) * inv_cell - 0.5);
-    b = (int)floor((ou + half - org) * inv_cell - 0.5);
-    if (!(a <= b && pred(a) && !pred(a - 1) && pred(b) && !pred(b + 1))) {
-        // rare: an estimate one off, or an empty run.  Find a true index next to the centre, then walk both ends.
-        int t;
-        if (pred(ic)) t = ic; else if (pred(ic - 1)) t = ic - 1; else if (pred(ic + 1)) t = ic + 1; else return false;
+    const double half = sqrt(R2 - dv2);                    // (double: a single-precision estimate misses the certificate too often)
+    a = clampi((int)ceil((ou - half - org) * inv_cell - 0.5), lo - 1, hi + 1);
+    b = clampi((int)floor((ou + half - org) * inv_cell - 0.5), lo - 1, hi + 1);
+    const bool pa = pred(a), pa1 = pred(a - 1), pb = pred(b), pb1 = pred(b + 1);          // four independent evaluations, no short-circuit
+    if (!((a <= b) & pa & !pa1 & pb & !pb1)) {
+        // an empty run (the common reason: the footprint only grazes the line), or - rarely - an estimate one off.  A run that
+        // is not empty contains the index nearest to ou: three evaluations certify emptiness; otherwise both ends are walked.
+        const bool c0 = pred(ic), c1 = pred(ic - 1), c2 = pred(ic + 1);
+        if (!(c0 | c1 | c2)) return false;
+        const int t = c0 ? ic : (c1 ? ic - 1 : ic + 1);
         a = min(a, t); b = max(b, t);
 #pragma nounroll
         for (int g = 0; g < 4096 && pred(a - 1); g++) a--;
@@ -278,6 +281,17 @@ __device__ __forceinline__ bool exact_span(double ou, double org, double cell, d
         for (int g = 0; g < 4096 && !pred(b); g++) b--;
     }
     a = max(a, lo); b = min(b, hi);
+    return a <= b;
+}
+
+// A superset of the exact run, without evaluating the predicate: the estimate widened by two cells on both sides (the line masks
+// built from it may flag a word that stays zero).  Empty only when the line is exactly empty.
+__device__ __forceinline__ bool rough_span(double ou, double org, double inv_cell, double dv2, double R2, int lo, int hi, int& a, int& b)
+{
+    if (dv2 > R2) return false;
+    const double half = (double)__builtin_sqrtf((float)(R2 - dv2));
+    a = max((int)floor((ou - half - org) * inv_cell) - 2, lo);
+    b = min((int)floor((ou + half - org) * inv_cell) + 2, hi);
     return a <= b;
 }
 
@@ -313,7 +327,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int tid, int* s_wave /* [k
 // line = y, positions x; column-major half: line = x, positions y).  All kSearchBlock threads.
 // A wave owns the obstacles wv, wv + 4, ...; it computes 64 footprints at once (one per lane: the divisions are paid once
 // per obstacle, not per line) and then walks them, lanes 0..31 on a footprint's rows and lanes 32..63 on its columns.
-template <class Emit>
+template <bool EXACT = true, class Emit>
 __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m, Emit&& emit)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -351,7 +365,9 @@ __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const Scen
             for (int l = l0 + l32; l <= l1; l += 32) {
                 const double dv = (org_v + ((double)l + 0.5) * cell) - ov;
                 int a, b;
-                if (exact_span(ou, org_u, cell, inv_cell, dv * dv, R2, ic, lo, hi, a, b)) emit(colhalf, l, a, b);
+                const bool any = EXACT ? exact_span(ou, org_u, cell, inv_cell, dv * dv, R2, ic, lo, hi, a, b)
+                                       : rough_span(ou, org_u, inv_cell, dv * dv, R2, lo, hi, a, b);
+                if (any) emit(colhalf, l, a, b);
             }
         }
     }
@@ -359,8 +375,8 @@ __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const Scen
 
 // Builds both sparse views of a scene from its obstacle list.  All kSearchBlock threads; returns the words the larger view
 // needs (> budget: nothing was filled, the views are unusable).
-//   pass 1: which words of which lines the footprints touch (the line masks say exactly which words are non-zero);
-//   offsets: exclusive prefix sum of the word counts over the lines;  pass 2: the same spans again, OR-ed into the words.
+//   pass 1: which words of which lines the footprints can touch (from the span estimates, widened: a superset);
+//   offsets: exclusive prefix sum of the word counts over the lines;  pass 2: the exact spans, OR-ed into the words.
 template <int K>
 __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m,
                                                   const SparseView<K>& vr, const SparseView<K>& vc, int budget, int* s_wave,
@@ -376,7 +392,7 @@ __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const 
     for (int l = tid; l < W; l += kSearchBlock) vc.clear_line(l);
     __syncthreads();
     mark(); mark();
-    for_each_span(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
+    for_each_span<false>(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
         const int wa = a >> 5, wb = b >> 5;
         const M bits = (M)((((M)2) << (wb - wa)) - (M)1) << wa;
         if (colhalf) vc.or_mask(l, bits); else vr.or_mask(l, bits);
@@ -403,8 +419,8 @@ __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const 
     for (int i = tid; i < total_c; i += kSearchBlock) vc.data[i] = 0;
     __syncthreads();
     mark();
-    for_each_span(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
-        const SparseView<K> vw = colhalf ? vc : vr;          // by value: per-lane field selects, no stack object
+    const SparseView<K> vw = (tid & 32) ? vc : vr;           // this lane's half, selected once (by value: per-lane field selects, no stack object)
+    for_each_span(c, si, obs, m, [&](bool, int l, int a, int b) {
         const LineM<M> lm = vw.line(l);
         for_words(a, b, [&](int w, uint32_t bits) {
             __hip_atomic_fetch_or(&vw.data[lm.off + popc_m((M)(lm.mask & ((((M)1) << w) - (M)1)))], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -152,7 +152,8 @@ int  pp_mean_points(pp_handle h, const GlobalPoint2D* in, int n_in, GlobalPoint2
 int  pp_create_new_path(pp_handle h, const GlobalPoint2D* path, int n, double offset, GlobalPoint2D* out);
 
 /* ---- measurement / multi-GPU plumbing --------------------------------------------------------- */
-/* When on, every kernel launch of pp_plan_tick is bracketed by HIP events on the stream it is launched on. */
+/* on = 1: every kernel launch of pp_plan_tick is bracketed by HIP events on the stream it is launched on; on = 2: only the
+ * search kernel (an event pair costs a few microseconds of queue time: 2 is what a throughput measurement wants); 0: off. */
 int   pp_set_profile(pp_handle h, int on);
 /* Sum of event-measured durations (ms) and launch count of kernel k since the last reset. */
 int   pp_get_kernel_ms(pp_handle h, int k, float* ms_total, int* launches);

@@ -646,7 +646,7 @@ def test_bench_two_ranks_rehearsal(dm, oracle, tmp_path):
     for rk in range(2):                                    # rank rk's shard is scenes rk*n .. rk*n + n - 1
         sc = dm.gen_scenes(cfg, rk * n, n, n_obs, junction_every=8)
         st = sc["state"].copy()
-        plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st, n_threads=threads, want_grid=True, n_ticks=warm + steps)
+        plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, sc, st, n_threads=threads, want_grid=True, n_ticks=line["ticks_run"])
         sl = slice(rk * n, (rk + 1) * n)
         bad = (compare(got["plan"][sl], plan_o, "plan") + compare(got["state"][sl], st, "state")
                + compare(got["grid_out"][sl], gout_o, "grid"))

@@ -183,13 +183,16 @@ int setup_grid_launch(pp_planner* h)
         const size_t room = (lds_max - static_lds - (size_t)h->search_meta_bytes) / 8;        // data words per view that fit at all
         const size_t dense = N / 32;                                                            // ... that a view can ever need
         h->lds_budget_max = (int)std::min(room, dense);
-        const void* fns[3] = { reinterpret_cast<const void*>(&dmpp::k_search<0>), reinterpret_cast<const void*>(&dmpp::k_search<1>),
-                               reinterpret_cast<const void*>(&dmpp::k_search<2>) };
+        const void* fns[3] = { reinterpret_cast<const void*>(&dmpp::k_search<0, dmpp::kSearchSetupWaves>), reinterpret_cast<const void*>(&dmpp::k_search<1, dmpp::kSearchSetupWaves>),
+                               reinterpret_cast<const void*>(&dmpp::k_search<2, dmpp::kSearchSetupWaves>) };
+        const void* fnw[3] = { reinterpret_cast<const void*>(&dmpp::k_search<0, dmpp::kSearchSetupWavesWide>), reinterpret_cast<const void*>(&dmpp::k_search<1, dmpp::kSearchSetupWavesWide>),
+                               reinterpret_cast<const void*>(&dmpp::k_search<2, dmpp::kSearchSetupWavesWide>) };
         const void* fne[3] = { reinterpret_cast<const void*>(&dmpp::k_export_grid<0>), reinterpret_cast<const void*>(&dmpp::k_export_grid<1>),
                                reinterpret_cast<const void*>(&dmpp::k_export_grid<2>) };
         const int dyn_max = std::max(h->search_meta_bytes + 8 * h->lds_budget_max, h->gbm_lds);
         if (dyn_max + (int)static_lds > 48 * 1024) {
             if (hipFuncSetAttribute(fns[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess ||
+                hipFuncSetAttribute(fnw[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess ||
                 hipFuncSetAttribute(fne[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess) {
                 (void)hipGetLastError();
                 h->lds_budget_max = (int)std::min((size_t)h->lds_budget_max, (48u * 1024u - static_lds - (size_t)h->search_meta_bytes) / 8);
@@ -622,13 +625,19 @@ int pp_plan_tick(pp_handle h)
             const int budget = h->search_force_gbm ? 0 : h->lds_budget;
             HIP_TRY(hipMemsetAsync(h->d_need[p], 0, sizeof(int32_t), sm));
             const size_t dyn = std::max((size_t)h->search_meta_bytes + 8 * (size_t)budget, (size_t)h->gbm_lds);
+            const bool wide = n <= kScoreWideMaxScenes;       // a few scenes: sixteen waves set each scene up (the latency-bound tick)
             {
                 Timed t(h, PP_K_SEARCH, sm);
                 switch (h->search_kind) {
 #define DMPP_LAUNCH_SEARCH(K)                                                                                                                  \
-                case K: hipLaunchKernelGGL(dmpp::k_search<K>, dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget, perm,  \
+                case K:                                                                                                                        \
+                    if (wide) hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWavesWide>), dim3(n), dim3(dmpp::kSearchSetupWavesWide * DMPP_WAVE), dyn, sm, c, n, h->caps.order_cap, budget, perm, \
                                            h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], \
-                                           h->d_cost[p], h->d_ovf[p], h->d_need[p]); break;
+                                           h->d_cost[p], h->d_ovf[p], h->d_need[p]);                                                         \
+                    else hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWaves>), dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget, perm,  \
+                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], \
+                                           h->d_cost[p], h->d_ovf[p], h->d_need[p]);                                                         \
+                    break;
                 DMPP_LAUNCH_SEARCH(0) DMPP_LAUNCH_SEARCH(1) DMPP_LAUNCH_SEARCH(2)
 #undef DMPP_LAUNCH_SEARCH
                 }

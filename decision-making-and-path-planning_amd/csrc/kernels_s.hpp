@@ -1,7 +1,7 @@
 // kernels_s.hpp — G2, the jump-point A* of the grid engine (specification: oracle/dmpp_grid_oracle.c, DESIGN.md §5;
 // the reference has no grid code).  ONE searching wave per scene.
 //
-//   k_search<K> : the scene's workgroup (4 waves) rasterises its own obstacle list straight into LDS as a SPARSE two-view
+//   k_search<K, SW> : the scene's workgroup (SW = 4 waves; 16 when few scenes have the chip to themselves) rasterises its own obstacle list straight into LDS as a SPARSE two-view
 //                 bitmap - row-major for E/W scans, column-major for N/S scans; per line a mask of the words that hold an
 //                 obstacle bit and the index of the line's first stored word (per-line CSR); only non-zero words are stored.
 //                 No occupancy grid crosses HBM, and a scene needs ~12 KB (64 obstacles) instead of 64 KB of bitmaps,
@@ -53,7 +53,8 @@ constexpr int kDiagK = DMPP_DIAG_JUMP;                  // cells a diagonal jump
 constexpr int kDiagGroup = 2 * kDiagK;                  // lanes per diagonal jump: (cell, horizontal | vertical component)
 constexpr int kDiagPerRound = DMPP_WAVE / kDiagGroup;
 constexpr int kMaxDiag = 16;                            // diagonal jumps of a step: <= 4 nodes x 4 (start) / x 3
-constexpr int kSearchSetupWaves = 4, kSearchBlock = kSearchSetupWaves * DMPP_WAVE;
+constexpr int kSearchSetupWaves = 4, kSearchBlock = kSearchSetupWaves * DMPP_WAVE;   // set-up waves per scene in a batch ...
+constexpr int kSearchSetupWavesWide = 16;                                             // ... and when a handful of scenes has the chip to itself
 constexpr int kOrderShift = 13;                         // search-time classes of 8 Ki cycles (k_order)
 constexpr int kOrderClasses = 1024;
 
@@ -270,15 +271,18 @@ __device__ __forceinline__ bool exact_span(double ou, double org, double cell, d
         const bool c0 = pred(ic), c1 = pred(ic - 1), c2 = pred(ic + 1);
         if (!(c0 | c1 | c2)) return false;
         const int t = c0 ? ic : (c1 ? ic - 1 : ic + 1);
-        a = min(a, t); b = max(b, t);
+        // the run contains t; outside the window [lo, hi] it only matters whether it reaches in
+        if ((t < lo && !pred(lo)) || (t > hi && !pred(hi))) return false;
+        a = clampi(min(a, t), lo - 1, hi + 1); b = clampi(max(b, t), lo - 1, hi + 1);
+        // every walk stays inside the window (plus one cell), so it is bounded by the width of the grid
 #pragma nounroll
-        for (int g = 0; g < 4096 && pred(a - 1); g++) a--;
+        while (a >= lo && pred(a - 1)) a--;
 #pragma nounroll
-        for (int g = 0; g < 4096 && !pred(a); g++) a++;
+        while (a <= hi && !pred(a)) a++;
 #pragma nounroll
-        for (int g = 0; g < 4096 && pred(b + 1); g++) b++;
+        while (b <= hi && pred(b + 1)) b++;
 #pragma nounroll
-        for (int g = 0; g < 4096 && !pred(b); g++) b--;
+        while (b >= lo && b >= a && !pred(b)) b--;
     }
     a = max(a, lo); b = min(b, hi);
     return a <= b;
@@ -307,7 +311,8 @@ __device__ __forceinline__ void for_words(int p0, int p1, F&& f)
 }
 
 // exclusive prefix sum over the 256 threads of the setup block (wave scan by shuffles, waves joined through LDS)
-__device__ __forceinline__ int block_excl_scan(int v, int tid, int* s_wave /* [kSearchSetupWaves + 1] */)
+template <int SW>
+__device__ __forceinline__ int block_excl_scan(int v, int tid, int* s_wave /* [SW + 1] */)
 {
     const int lane = tid & 63, wv = tid >> 6;
     int incl = v;
@@ -316,8 +321,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int tid, int* s_wave /* [k
     if (lane == DMPP_WAVE - 1) s_wave[wv] = incl;
     __syncthreads();
     int base = 0, total = 0;
-    for (int q = 0; q < kSearchSetupWaves; q++) { const int t = s_wave[q]; if (q < wv) base += t; total += t; }
-    if (tid == 0) s_wave[kSearchSetupWaves] = total;
+    for (int q = 0; q < SW; q++) { const int t = s_wave[q]; if (q < wv) base += t; total += t; }
+    if (tid == 0) s_wave[SW] = total;
     __syncthreads();
     return base + incl - v;
 }
@@ -327,7 +332,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int tid, int* s_wave /* [k
 // line = y, positions x; column-major half: line = x, positions y).  All kSearchBlock threads.
 // A wave owns the obstacles wv, wv + 4, ...; it computes 64 footprints at once (one per lane: the divisions are paid once
 // per obstacle, not per line) and then walks them, lanes 0..31 on a footprint's rows and lanes 32..63 on its columns.
-template <bool EXACT = true, class Emit>
+template <int SW, bool EXACT = true, class Emit>
 __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m, Emit&& emit)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -341,11 +346,11 @@ __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const Scen
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
         return __hiloint2double(hi, lo);
     };
-    for (int base = 0; base < m; base += kSearchSetupWaves * DMPP_WAVE) {
+    for (int base = 0; base < m; base += SW * DMPP_WAVE) {
         // this lane's obstacle of the chunk
         Footprint f; f.ox = f.oy = f.R2 = 0; f.ix0 = f.iy0 = 0; f.ix1 = f.iy1 = -1;
         int icx = 0, icy = 0;
-        const int j = base + wv + kSearchSetupWaves * lane;
+        const int j = base + wv + SW * lane;
         if (j < m) {
             f = footprint_of(c, origin, obs[j], W, H);
             icx = (int)floor((f.ox - origin.x) / cell);
@@ -353,7 +358,7 @@ __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const Scen
         }
         const unsigned long long anym = __ballot(j < m && f.ix1 >= f.ix0 && f.iy1 >= f.iy0);
         const int left = m - base - wv;
-        const int cnt = left <= 0 ? 0 : min(DMPP_WAVE, (left + kSearchSetupWaves - 1) / kSearchSetupWaves);
+        const int cnt = left <= 0 ? 0 : min(DMPP_WAVE, (left + SW - 1) / SW);
         for (int q = 0; q < cnt; q++) {
             if (!((anym >> q) & 1ull)) continue;
             const double fx = bcast_d(f.ox, q), fy = bcast_d(f.oy, q), R2 = bcast_d(f.R2, q);
@@ -377,7 +382,7 @@ __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const Scen
 // needs (> budget: nothing was filled, the views are unusable).
 //   pass 1: which words of which lines the footprints can touch (from the span estimates, widened: a superset);
 //   offsets: exclusive prefix sum of the word counts over the lines;  pass 2: the exact spans, OR-ed into the words.
-template <int K>
+template <int K, int SW>
 __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m,
                                                   const SparseView<K>& vr, const SparseView<K>& vc, int budget, int* s_wave,
                                                   long long* tmark = nullptr)
@@ -388,11 +393,11 @@ __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const 
     int tm_i = 0;
     auto mark = [&]() { if (tmark) tmark[tm_i++] = clock64(); };
     mark();
-    for (int l = tid; l < H; l += kSearchBlock) vr.clear_line(l);
-    for (int l = tid; l < W; l += kSearchBlock) vc.clear_line(l);
+    for (int l = tid; l < H; l += (SW * DMPP_WAVE)) vr.clear_line(l);
+    for (int l = tid; l < W; l += (SW * DMPP_WAVE)) vc.clear_line(l);
     __syncthreads();
     mark(); mark();
-    for_each_span<false>(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
+    for_each_span<SW, false>(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
         const int wa = a >> 5, wb = b >> 5;
         const M bits = (M)((((M)2) << (wb - wa)) - (M)1) << wa;
         if (colhalf) vc.or_mask(l, bits); else vr.or_mask(l, bits);
@@ -401,12 +406,12 @@ __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const 
     mark();
     // ---- offsets: exclusive prefix sum of the word counts over the lines, per view ----
     auto place = [&](const SparseView<K>& vw) {
-        const int NL = vw.NL, per = (NL + kSearchBlock - 1) / kSearchBlock;
+        const int NL = vw.NL, per = (NL + (SW * DMPP_WAVE) - 1) / (SW * DMPP_WAVE);
         const int l0 = tid * per, l1 = min(l0 + per, NL);
         int cnt = 0;
         for (int l = l0; l < l1; l++) cnt += popc_m(vw.mask_of(l));
-        int off = block_excl_scan(cnt, tid, s_wave);
-        const int total = s_wave[kSearchSetupWaves];
+        int off = block_excl_scan<SW>(cnt, tid, s_wave);
+        const int total = s_wave[SW];
         for (int l = l0; l < l1; l++) { const int k = popc_m(vw.mask_of(l)); vw.set_off(l, (uint32_t)off); off += k; }
         __syncthreads();
         return total;
@@ -415,12 +420,12 @@ __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const 
     const int need = max(total_r, total_c);
     mark();
     if (need > budget) return need;
-    for (int i = tid; i < total_r; i += kSearchBlock) vr.data[i] = 0;
-    for (int i = tid; i < total_c; i += kSearchBlock) vc.data[i] = 0;
+    for (int i = tid; i < total_r; i += (SW * DMPP_WAVE)) vr.data[i] = 0;
+    for (int i = tid; i < total_c; i += (SW * DMPP_WAVE)) vc.data[i] = 0;
     __syncthreads();
     mark();
     const SparseView<K> vw = (tid & 32) ? vc : vr;           // this lane's half, selected once (by value: per-lane field selects, no stack object)
-    for_each_span(c, si, obs, m, [&](bool, int l, int a, int b) {
+    for_each_span<SW>(c, si, obs, m, [&](bool, int l, int a, int b) {
         const LineM<M> lm = vw.line(l);
         for_words(a, b, [&](int w, uint32_t bits) {
             __hip_atomic_fetch_or(&vw.data[lm.off + popc_m((M)(lm.mask & ((((M)1) << w) - (M)1)))], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -434,6 +439,7 @@ __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const 
 // The dense form of the same two views, in HBM: H x W/32 words row-major at bm, W x H/32 words column-major behind them;
 // one u64 per line in LDS says which words are non-zero.  Only for the scenes whose non-zero words do not fit the LDS
 // budget of the launch.  All kSearchBlock threads.
+template <int SW>
 __device__ __forceinline__ void build_dense_views(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m,
                                                   uint32_t* __restrict__ bm, DMPP_LDS uint64_t* nz_row, DMPP_LDS uint64_t* nz_col)
 {
@@ -443,11 +449,11 @@ __device__ __forceinline__ void build_dense_views(const PlannerConfig& c, const 
     {
         uint4* z4 = reinterpret_cast<uint4*>(bm);
         const uint4 z = { 0u, 0u, 0u, 0u };
-        for (int i = tid; i < (2 * NW) >> 2; i += kSearchBlock) z4[i] = z;
+        for (int i = tid; i < (2 * NW) >> 2; i += (SW * DMPP_WAVE)) z4[i] = z;
     }
     __threadfence();
     __syncthreads();
-    for_each_span(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
+    for_each_span<SW>(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
         uint32_t* line = colhalf ? bmT + (size_t)l * HW : bm + (size_t)l * WW;
         for_words(a, b, [&](int w, uint32_t bits) { atomicOr(&line[w], bits); });
     });
@@ -457,7 +463,7 @@ __device__ __forceinline__ void build_dense_views(const PlannerConfig& c, const 
         const uint32_t* src = v ? bmT : bm;
         DMPP_LDS uint64_t* nz = v ? nz_col : nz_row;
         const int LW = v ? HW : WW, NL = v ? W : H;
-        for (int line = tid; line < NL; line += kSearchBlock) {
+        for (int line = tid; line < NL; line += (SW * DMPP_WAVE)) {
             uint64_t msk = 0;
             for (int w = 0; w < LW; w++) msk |= (uint64_t)min(src[line * LW + w], 1u) << w;
             nz[line] = msk;
@@ -477,18 +483,30 @@ __device__ __forceinline__ void sparse_clear_cell(const SparseView<K>& vw, int l
 }
 
 // ---------------------------------------------------------------------------------------
-struct SearchLds {                               // the static LDS of a searching workgroup (10.3 KB)
+struct SearchLds {                               // the static LDS of a searching workgroup (12.3 KB)
     uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24
     uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
     uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
     uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
     uint16_t c_info[kClosedTab];    // arriving direction | run length << 4 of the cell in the same slot
+    uint16_t c_seq[kClosedTab];     // its expansion number (0xFFFF: inserted but never expanded - the search ended in that step)
     uint32_t job[kMaxDiag + 8];     // the jumps of the current step, x | y << 12 | s << 24: diagonal ones (<= 16), then straight ones (<= 8)
-    int s_wave[kSearchSetupWaves + 1];
+    int s_wave[kSearchSetupWavesWide + 1];
     int s_flag;
 };
 
 struct SearchOut { int status, n_exp, n_push, n_rounds, path_cost, path_len; uint64_t digest; };
+
+// order_digest of the expansions recorded in the closed-set hash: this lane's share of  sum mix64(seq << 32 | cell)
+__device__ __forceinline__ uint64_t hash_digest(const SearchLds& L, int lane)
+{
+    uint64_t dg = 0;
+    for (int i = lane; i < kClosedTab; i += DMPP_WAVE) {
+        const uint32_t e = L.c_tab[i]; const uint32_t sq = L.c_seq[i];
+        if (e && sq != 0xFFFFu) dg += mix64(((uint64_t)sq << 32) | (uint64_t)(e - 1u));
+    }
+    return dg;
+}
 
 // Squeezes the dead slots out of the open list, keeping the push order (ballot + prefix popcount); the slots that fall free
 // are marked dead again (the pop relies on 0xFFFF at and beyond n_open).  Returns the new n_open.
@@ -631,13 +649,14 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
             if ((node == 1 && cell == c0_) || (node == 2 && (cell == c0_ || cell == c1_)) ||
                 (node == 3 && (cell == c0_ || cell == c1_ || cell == c2_))) valid = false;
         }
+        uint32_t my_slot = 0;
         if (n_exp + DMPP_JPS_BATCH <= kClosedMax) {
             if (valid) {
                 const uint32_t keyc = (uint32_t)cell + 1u;
                 uint32_t hh = ((uint32_t)cell * 2654435761u) >> (32 - kClosedLog);
                 for (int probe = 0; probe < kClosedTab; probe++) {
                     const uint32_t old = atomicCAS(&L.c_tab[hh], 0u, keyc);
-                    if (old == 0u) { L.c_info[hh] = (uint16_t)(d | (run_in << 4)); break; }   // inserted: was open
+                    if (old == 0u) { L.c_info[hh] = (uint16_t)(d | (run_in << 4)); L.c_seq[hh] = 0xFFFFu; my_slot = hh; break; }   // inserted: was open
                     if (old == keyc) { valid = false; break; }            // already closed
                     hh = (hh + 1) & (kClosedTab - 1);
                 }
@@ -647,6 +666,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
                 // ---- spill: this scene outgrows the LDS hash.  Its bit set in HBM is zeroed now, not at launch (most scenes
                 //      never get here), the hash is replayed into it, and from here on the bit set answers. ----
                 hash_complete = false;
+                digest += hash_digest(L, lane);             // the expansions so far (from here on the digest is kept step by step)
                 uint4* c4 = reinterpret_cast<uint4*>(closed);
                 const uint4 z = { 0u, 0u, 0u, 0u };
                 for (int i = lane; i < (N >> 7); i += DMPP_WAVE) c4[i] = z;
@@ -678,9 +698,9 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
         }
         if (valid) {
             const int seq = n_exp + __popc(vm & ((1u << node) - 1u));
-            if (!hash_complete) pin[cell] = (uint16_t)(d | (run_in << 4));
+            if (hash_complete) L.c_seq[my_slot] = (uint16_t)seq;      // the digest is summed from the hash at the end: 64 lanes at once, off the chain of steps
+            else { pin[cell] = (uint16_t)(d | (run_in << 4)); digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell); }
             if (order && seq < order_cap) order[seq] = cell;
-            digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell);
         }
         if (vm && f > fmax) { fmax = f; n_rounds++; }
         n_exp += __popc(vm);
@@ -790,7 +810,8 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
     }
     DBG_MARK(5)
 
-    // ---- reduce the digest, rebuild the path from the runs ----
+    // ---- the digest (from the hash unless the scene spilled), reduced over the wave; then the path from the runs ----
+    if (hash_complete) digest += hash_digest(L, lane);
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) {
         uint32_t lo = (uint32_t)digest, hi = (uint32_t)(digest >> 32);
@@ -960,8 +981,8 @@ __device__ __forceinline__ void publish_debug(int32_t* path, int max_path, const
 //   = 1) rasterises the dense form into gbitmaps (HBM) and is searched there - same loop, slower reads.  budget = 0 sends
 //   every scene that way (test knob).
 //   need_max: running maximum of the words a scene needed (the host sizes the next launches from it).
-template <int K>
-__global__ void __launch_bounds__(kSearchBlock)
+template <int K, int SW>
+__global__ void __launch_bounds__(SW * DMPP_WAVE)
 k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
          const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
          int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out,
@@ -994,21 +1015,21 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t
         vr.data = (DMPP_LDS uint32_t*)(p + used); vc.data = vr.data + budget;
         vr.LW = WW; vr.NL = H; vc.LW = HW; vc.NL = W;
     }
-    for (int i = tid; i < kClosedTab; i += kSearchBlock) L.c_tab[i] = 0;
-    for (int i = tid; i < kOpenCap; i += kSearchBlock) L.o_f2[i] = 0xFFFFu;      // dead slots everywhere: the pop never range-checks
+    for (int i = tid; i < kClosedTab; i += (SW * DMPP_WAVE)) L.c_tab[i] = 0;
+    for (int i = tid; i < kOpenCap; i += (SW * DMPP_WAVE)) L.o_f2[i] = 0xFFFFu;      // dead slots everywhere: the pop never range-checks
     const ObPoint* obs = obs_now + si.obs_off;
 #ifdef DMPP_DEBUG_SEARCH
     long long tmark[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    const int need = budget > 0 ? build_sparse_views<K>(c, si, obs, si.obs_n, vr, vc, budget, L.s_wave, tmark) : 1;
+    const int need = budget > 0 ? build_sparse_views<K, SW>(c, si, obs, si.obs_n, vr, vc, budget, L.s_wave, tmark) : 1;
 #else
-    const int need = budget > 0 ? build_sparse_views<K>(c, si, obs, si.obs_n, vr, vc, budget, L.s_wave) : 1;
+    const int need = budget > 0 ? build_sparse_views<K, SW>(c, si, obs, si.obs_n, vr, vc, budget, L.s_wave) : 1;
 #endif
     const bool dense = need > budget;          // uniform over the block
     if (tid == 0) { if (budget > 0) atomicMax(need_max, need); overflow[scene] = dense ? 1 : 0; }
     uint32_t* bm = gbitmaps + (size_t)scene * 2 * (N >> 5);
     DMPP_LDS uint64_t* nz_row = (DMPP_LDS uint64_t*)smem_raw;
     DMPP_LDS uint64_t* nz_col = nz_row + H;
-    if (dense) { __syncthreads(); build_dense_views(c, si, obs, si.obs_n, bm, nz_row, nz_col); }
+    if (dense) { __syncthreads(); build_dense_views<SW>(c, si, obs, si.obs_n, bm, nz_row, nz_col); }
     const DenseView dr{ bm, nz_row, WW, H }, dc{ bm + (N >> 5), nz_col, HW, W };
     const int start = cell_of(c, si.grid_origin, si.loc.globalpoint.x, si.loc.globalpoint.y);
     const int goal = cell_of(c, si.grid_origin, si.goal.x, si.goal.y);
@@ -1090,13 +1111,13 @@ k_export_grid(PlannerConfig c, int scene, int budget, const SceneIn* __restrict_
         vr.LW = WW; vr.NL = H; vc.LW = HW; vc.NL = W;
     }
     const ObPoint* obs = obs_now + si.obs_off;
-    const int need = build_sparse_views<K>(c, si, obs, si.obs_n, vr, vc, budget, s_wave);
+    const int need = build_sparse_views<K, kSearchSetupWaves>(c, si, obs, si.obs_n, vr, vc, budget, s_wave);
     if (need > budget) {
         if (tid == 0) bad[1] = 1;
         for (int cell = tid; cell < W * H; cell += kSearchBlock) out[cell] = 0;
         __threadfence();
         __syncthreads();
-        for_each_span(c, si, obs, si.obs_n, [&](bool colhalf, int l, int a, int b) {
+        for_each_span<kSearchSetupWaves>(c, si, obs, si.obs_n, [&](bool colhalf, int l, int a, int b) {
             if (!colhalf) for (int x = a; x <= b; x++) out[l * W + x] = 1;
         });
         return;

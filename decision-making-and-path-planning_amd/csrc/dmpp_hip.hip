@@ -74,7 +74,6 @@ struct pp_planner {
     hipEvent_t ev_raster = nullptr;
     bool score_recorded[kBuf] = {}, search_recorded[kBuf] = {}, front_recorded = false, front_unjoined = false;
     int parity = 0;              // buffers of the last tick
-    bool fuse_score = false;         // env DMPP_FUSE_SCORE=1: G3 inside k_search (the scene's own workgroup scores it right after its search)
     bool score_own_stream = false;   // env DMPP_SCORE_STREAM=1 (measurement knob): k_score on one stream of its own
     int n_cus = 256;
     int pipeline_min = 256;      // batches at least this large run the three chains on three streams (env DMPP_PIPELINE_MIN)
@@ -171,7 +170,7 @@ int setup_grid_launch(pp_planner* h)
     h->search_kind = lw <= 16 ? 0 : (lw <= 32 ? 1 : 2);
     const size_t per_line = h->search_kind == 0 ? 4 : (h->search_kind == 1 ? 8 : 12);
     h->search_meta_bytes = (int)((((size_t)c.grid_w + c.grid_h) * per_line + 15) & ~(size_t)15);
-    const size_t static_lds = (sizeof(dmpp::SearchLds) + 15) & ~(size_t)15;     // (the search keeps its SearchLds at the head of its dynamic LDS)
+    const size_t static_lds = sizeof(dmpp::SearchLds) + 64;
     size_t lds_max = 64u * 1024u;
     {
         int v = 0;
@@ -191,8 +190,8 @@ int setup_grid_launch(pp_planner* h)
                                reinterpret_cast<const void*>(&dmpp::k_search<2, dmpp::kSearchSetupWavesWide>) };
         const void* fne[3] = { reinterpret_cast<const void*>(&dmpp::k_export_grid<0>), reinterpret_cast<const void*>(&dmpp::k_export_grid<1>),
                                reinterpret_cast<const void*>(&dmpp::k_export_grid<2>) };
-        const int dyn_max = (int)std::max<size_t>(static_lds + (size_t)std::max(h->search_meta_bytes + 8 * h->lds_budget_max, h->gbm_lds), sizeof(dmpp::ScoreShared<16>));
-        if (dyn_max > 48 * 1024) {
+        const int dyn_max = std::max(h->search_meta_bytes + 8 * h->lds_budget_max, h->gbm_lds);
+        if (dyn_max + (int)static_lds > 48 * 1024) {
             if (hipFuncSetAttribute(fns[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess ||
                 hipFuncSetAttribute(fnw[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess ||
                 hipFuncSetAttribute(fne[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess) {
@@ -201,10 +200,6 @@ int setup_grid_launch(pp_planner* h)
             }
         }
     }
-    // G3 inside k_search (the scene's own workgroup scores it right after its search) saves a launch and 5 % of the tick, but puts the
-    // scoring of the slowest scene on the end of the search kernel (0.74 -> 0.88 ms per launch) and costs 10 us at batch 1: off by default
-    h->fuse_score = false;
-    if (const char* e = std::getenv("DMPP_FUSE_SCORE")) h->fuse_score = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMPP_SEARCH_GBM")) h->search_force_gbm = std::atoi(e) != 0;          // test / measurement knob: the dense form in HBM for every scene
     if (const char* e = std::getenv("DMPP_LDS_BUDGET")) {                                                // ... a fixed budget (words per view)
         h->lds_budget = std::max(1, std::min(std::atoi(e), h->lds_budget_max)); h->lds_budget_fixed = true;
@@ -573,12 +568,11 @@ int pp_plan_tick(pp_handle h)
             }
             h->lds_budget = std::max(64, std::min(want, h->lds_budget_max));
         }
-        const size_t per_wg = std::max(((sizeof(dmpp::SearchLds) + 15) & ~(size_t)15) + std::max((size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget, (size_t)h->gbm_lds),
-                                       h->fuse_score ? sizeof(dmpp::ScoreShared<4>) : (size_t)0);
+        const size_t per_wg = sizeof(dmpp::SearchLds) + 64 + std::max((size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget, (size_t)h->gbm_lds);
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / per_wg));       // 4 waves per workgroup while it sets up: <= 8 per CU
         h->search_slots = per_cu * std::max(1, h->n_cus);
     } else if (c.grid_stage) {
-        const size_t per_wg = ((sizeof(dmpp::SearchLds) + 15) & ~(size_t)15) + (size_t)h->gbm_lds;
+        const size_t per_wg = sizeof(dmpp::SearchLds) + 64 + (size_t)h->gbm_lds;
         h->search_slots = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / per_wg)) * std::max(1, h->n_cus);
     }
     // Consecutive searches overlap: a search ends with a handful of long scenes and would leave most of the chip idle; the searches
@@ -587,7 +581,7 @@ int pp_plan_tick(pp_handle h)
     if (h->overlap_override >= 0) overlap = piped && h->overlap_override != 0;      // env DMPP_OVERLAP (measurement knob)
     hipStream_t sm = overlap ? h->stream_m[p] : h->stream;             // search chain
     hipStream_t sf = piped ? h->stream_r : h->stream;                  // front chain
-    hipStream_t ss = piped ? (((overlap && !h->score_own_stream) || h->fuse_score) ? sm : h->stream_s) : h->stream; // score chain: behind its own search when the searches overlap
+    hipStream_t ss = piped ? ((overlap && !h->score_own_stream) ? sm : h->stream_s) : h->stream; // score chain: behind its own search when the searches overlap
     hipStream_t sr = c.grid_stage ? h->stream_r : h->stream;           // Decision + Planning
     if (h->score_recorded[p]) { HIP_TRY(hipStreamWaitEvent(sf, h->ev_score[p], 0)); HIP_TRY(hipStreamWaitEvent(sm, h->ev_score[p], 0)); }
     if (h->search_recorded[p]) HIP_TRY(hipStreamWaitEvent(sf, h->ev_search[p], 0));
@@ -632,19 +626,17 @@ int pp_plan_tick(pp_handle h)
         {
             const int budget = h->search_force_gbm ? 0 : h->lds_budget;
             HIP_TRY(hipMemsetAsync(h->d_need[p], 0, sizeof(int32_t), sm));
-            const bool wide = n <= kScoreWideMaxScenes;       // a few scenes: sixteen waves set each scene up and score it (the latency-bound tick)
-            const int fuse = h->fuse_score ? 1 : 0;
-            size_t dyn = ((sizeof(dmpp::SearchLds) + 15) & ~(size_t)15) + std::max((size_t)h->search_meta_bytes + 8 * (size_t)budget, (size_t)h->gbm_lds);
-            if (fuse) dyn = std::max(dyn, wide ? sizeof(dmpp::ScoreShared<16>) : sizeof(dmpp::ScoreShared<4>));
+            const bool wide = n <= kScoreWideMaxScenes;       // a few scenes: sixteen waves set each scene up (the latency-bound tick)
+            const size_t dyn = std::max((size_t)h->search_meta_bytes + 8 * (size_t)budget, (size_t)h->gbm_lds);
             {
                 Timed t(h, PP_K_SEARCH, sm);
                 switch (h->search_kind) {
 #define DMPP_LAUNCH_SEARCH(K)                                                                                                                  \
                 case K:                                                                                                                        \
-                    if (wide) hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWavesWide>), dim3(n), dim3(dmpp::kSearchSetupWavesWide * DMPP_WAVE), dyn, sm, c, n, h->caps.order_cap, budget, fuse, perm, \
+                    if (wide) hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWavesWide>), dim3(n), dim3(dmpp::kSearchSetupWavesWide * DMPP_WAVE), dyn, sm, c, n, h->caps.order_cap, budget, perm, \
                                            h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], \
                                            h->d_cost[p], h->d_ovf[p], h->d_need[p]);                                                         \
-                    else hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWaves>), dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget, fuse, perm,  \
+                    else hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWaves>), dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget, perm,  \
                                            h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], \
                                            h->d_cost[p], h->d_ovf[p], h->d_need[p]);                                                         \
                     break;
@@ -660,7 +652,7 @@ int pp_plan_tick(pp_handle h)
         }
         h->search_recorded[p] = piped;                   // (one-stream mode: stream order is enough, no events on the latency path)
         if (piped) { HIP_TRY(hipEventRecord(h->ev_search[p], sm)); HIP_TRY(hipStreamWaitEvent(ss, h->ev_search[p], 0)); }
-        if (!h->fuse_score) {
+        {
             Timed t(h, PP_K_SCORE, ss);
             if (n <= kScoreWideMaxScenes)     // few scenes: sixteen waves per scene (17 candidates in two rounds)
                 hipLaunchKernelGGL(dmpp::k_score<16>, dim3(n), dim3(16 * DMPP_WAVE), sizeof(dmpp::ScoreShared<16>), ss, c, n, h->d_in, obs_now,

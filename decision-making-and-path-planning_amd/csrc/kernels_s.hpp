@@ -22,7 +22,6 @@
 #pragma once
 #include <type_traits>
 #include "dev_geom.hpp"
-#include "kernels_score.hpp"
 
 namespace dmpp {
 
@@ -984,16 +983,15 @@ __device__ __forceinline__ void publish_debug(int32_t* path, int max_path, const
 //   need_max: running maximum of the words a scene needed (the host sizes the next launches from it).
 template <int K, int SW>
 __global__ void __launch_bounds__(SW * DMPP_WAVE)
-k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, int fuse_score, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
+k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
          const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
          int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out,
          int32_t* __restrict__ overflow, int32_t* __restrict__ need_max)
 {
-    // dynamic LDS: [SearchLds | line metas of both views | `budget` data words per view]; the scoring pass at the end lays its
-    // ScoreShared over all of it (the host sizes the allocation for whichever is larger)
+    // static LDS: SearchLds; dynamic LDS: [line metas of both views | `budget` data words per view]
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    SearchLds& L = *reinterpret_cast<SearchLds*>(smem_raw);
-    constexpr unsigned kViewsAt = (unsigned)((sizeof(SearchLds) + 15) & ~(size_t)15);
+    __shared__ SearchLds L;
+    constexpr unsigned kViewsAt = 0;
     if ((int)blockIdx.x >= n_scenes) return;
     const long long t_begin = clock64();
     const int scene = perm ? perm[blockIdx.x] : (int)blockIdx.x;      // heaviest scenes first (k_order) when they do not all fit at once
@@ -1054,42 +1052,31 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, int fuse_scor
     }
     __syncthreads();
     int32_t* path = paths + (size_t)scene * c.max_path;
-    if (wv == 0) {                             // set-up done: the search is wave 0's; the other waves wait at the barrier below
-        __builtin_amdgcn_s_setprio(1);         // a latency-bound wave: ahead of the set-up waves and of the kernels that run beside it
-        const long long t_setup = clock64() - t_begin;
-        SearchOut R; R.status = DMPP_G_GOAL_BLOCKED; R.n_exp = 0; R.n_push = 0; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
-        uint32_t* closed = gclosed + (size_t)scene * (N >> 5);
-        uint16_t* pin = pinfo + (size_t)scene * N;
-        int32_t* order = orders ? orders + (size_t)scene * order_cap : nullptr;
+    if (wv != 0) return;                       // set-up done: the search is wave 0's
+    __builtin_amdgcn_s_setprio(1);             // a latency-bound wave: ahead of the set-up waves and of the kernels that run beside it
+    const long long t_setup = clock64() - t_begin;
+    SearchOut R; R.status = DMPP_G_GOAL_BLOCKED; R.n_exp = 0; R.n_push = 0; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
+    uint32_t* closed = gclosed + (size_t)scene * (N >> 5);
+    uint16_t* pin = pinfo + (size_t)scene * N;
+    int32_t* order = orders ? orders + (size_t)scene * order_cap : nullptr;
 #ifdef DMPP_DEBUG_SEARCH
-        long long dbg_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int dbg_c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        if (!goal_blocked) R = dense ? search_core(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, lane, dbg_t, dbg_c)
-                                     : search_core(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, lane, dbg_t, dbg_c);
-        if (lane == 0) {
-            publish_debug(path, c.max_path, dbg_t, dbg_c, t_setup, clock64() - t_begin);
-            int32_t* d2 = path + c.max_path - 32;      // set-up phases: entry->clear, (unused x2), pass 1, offsets, zero, pass 2, tail
-            d2[0] = (int)(tmark[0] - t_begin); for (int i = 1; i < 7; i++) d2[i] = (int)(tmark[i] - tmark[i - 1]); d2[7] = (int)(t_begin + t_setup - tmark[6]);
-        }
-#else
-        if (!goal_blocked) R = dense ? search_core(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, lane)
-                                     : search_core(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, lane);
-#endif
-        (void)t_setup;
-        if (lane == 0) {
-            cost_out[scene] = (int32_t)min((clock64() - t_begin) >> kOrderShift, (long long)(kOrderClasses - 1));   // launch-order key of the next tick (k_order)
-            publish_search(gout[scene], R, start, goal);
-            L.s_wave[0] = R.status; L.s_wave[1] = R.path_len;
-        }
-        __threadfence();                       // the path cells are read by the other waves of this workgroup below
-        __builtin_amdgcn_s_setprio(0);
+    long long dbg_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int dbg_c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (!goal_blocked) R = dense ? search_core(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, lane, dbg_t, dbg_c)
+                                 : search_core(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, lane, dbg_t, dbg_c);
+    if (lane == 0) {
+        publish_debug(path, c.max_path, dbg_t, dbg_c, t_setup, clock64() - t_begin);
+        int32_t* d2 = path + c.max_path - 32;      // set-up phases: entry->clear, (unused x2), pass 1, offsets, zero, pass 2, tail
+        d2[0] = (int)(tmark[0] - t_begin); for (int i = 1; i < 7; i++) d2[i] = (int)(tmark[i] - tmark[i - 1]); d2[7] = (int)(t_begin + t_setup - tmark[6]);
     }
-    if (!fuse_score) return;
-    // ---- G3 for the scene just searched, by all waves of the workgroup (they have been parked at this barrier: no issue slots
-    //      used); ScoreShared lies over the search's LDS, which is dead now ----
-    __syncthreads();
-    const int status = L.s_wave[0], path_len = L.s_wave[1];
-    __syncthreads();
-    score_body<SW>(c, si, obs, si.obs_n, path, gout[scene], status, path_len, *reinterpret_cast<ScoreShared<SW>*>(smem_raw));
+#else
+    if (!goal_blocked) R = dense ? search_core(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, lane)
+                                 : search_core(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, lane);
+#endif
+    (void)t_setup;
+    if (lane == 0) {
+        cost_out[scene] = (int32_t)min((clock64() - t_begin) >> kOrderShift, (long long)(kOrderClasses - 1));   // launch-order key of the next tick (k_order)
+        publish_search(gout[scene], R, start, goal);
+    }
 }
 
 // pp_get_grid: one scene's occupancy grid as bytes, produced by the SAME footprint code the search uses (so the tests see

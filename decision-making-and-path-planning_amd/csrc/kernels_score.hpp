@@ -166,13 +166,14 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
                     const double dis1 = seg[i - 1], dis2 = seg[i];
                     const double dis3 = sqrt((pa.x - pf.x) * (pa.x - pf.x) + (pa.y - pf.y) * (pa.y - pf.y));
                     const double den = 2 * dis1 * dis2;
-                    double R = 1000;
+                    // curvature 1 / R with R = 0.5 * dis3 / sinA (fenced to 1000), as one division: sinA / (0.5 * dis3) - the
+                    // oracle's 1 / (0.5 * dis3 / sinA) to an ulp or two (the scores are compared to 1e-6)
+                    double kk = 0.001;
                     if (den > 0) {
                         const double cosA = (dis1 * dis1 + dis2 * dis2 - dis3 * dis3) / den;
                         const double sinA = sqrt(1 - cosA * cosA);
-                        if (sinA >= 0.001) R = 0.5 * dis3 / sinA;
+                        if (sinA >= 0.001) kk = sinA / (0.5 * dis3);
                     }
-                    const double kk = 1 / R;
                     k2_acc += kk * kk;
                 }
             }

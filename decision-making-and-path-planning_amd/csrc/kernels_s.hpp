@@ -48,7 +48,7 @@ __device__ __forceinline__ int hfun(int x, int y, int gx, int gy)
 }
 
 constexpr int kOpenCap = DMPP_OPEN_CAP;
-constexpr int kClosedLog = 10, kClosedTab = 1 << kClosedLog, kClosedMax = 768;      // LDS closed-set hash; beyond kClosedMax the scene spills to HBM
+constexpr int kClosedLog = 9, kClosedTab = 1 << kClosedLog, kClosedMax = 384;      // LDS closed-set hash; beyond kClosedMax the scene spills to HBM
 constexpr int kDiagK = DMPP_DIAG_JUMP;                  // cells a diagonal jump looks ahead
 constexpr int kDiagGroup = 2 * kDiagK;                  // lanes per diagonal jump: (cell, horizontal | vertical component)
 constexpr int kDiagPerRound = DMPP_WAVE / kDiagGroup;

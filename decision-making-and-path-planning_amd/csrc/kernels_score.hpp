@@ -8,16 +8,17 @@ namespace dmpp {
 // G3.  256 threads = 4 waves per scene; wave w scores candidates w, w+4, ...
 // NW waves per scene score the candidates NW at a time: 4 for batches (four scenes per CU), 16 for the few scenes of a
 // latency-bound tick (17 candidates in 2 rounds instead of 5).
+constexpr int kBoxWaves = 4;
 constexpr int kMaxRelObs = 128;      // culled obstacle list kept in LDS; a scene with more candidates near its paths reads the whole list from HBM
 template <int NW>
 struct ScoreShared {
     GlobalPoint2D cand[NW][DMPP_PATH_POINTS];
-    double seg[NW][DMPP_PATH_POINTS];        // |P_i - P_{i+1}| of the wave's current candidate
     GlobalPoint2D pts[DMPP_PATH_POINTS];     // grid-path prefix in metres (lookahead_cells+1 <= 200)
     double cum[DMPP_PATH_POINTS];
     double rx[kMaxRelObs], ry[kMaxRelObs], rr[kMaxRelObs], rt2[kMaxRelObs];   // obstacles that can matter: x, y, radius, cutoff^2
     double bx0[DMPP_MAX_LATTICE], bx1[DMPP_MAX_LATTICE], by0[DMPP_MAX_LATTICE], by1[DMPP_MAX_LATTICE];
     double cost[DMPP_MAX_LATTICE];
+    int box[4][4];                           // per wave: min / max cell column and row of the grid-path prefix
     int best, n_rel;
 };
 
@@ -53,10 +54,22 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
             GlobalPoint2D P0 = { si.grid_origin.x + ((double)(p0 % W) + 0.5) * c.cell, si.grid_origin.y + ((double)(p0 / W) + 0.5) * c.cell };
             thT = GetRoadAngle(c, P0, T);
         }
+        // the prefix in metres, and the box of its cells (per wave here, combined below): the path candidate lies inside it
+        int cx0 = 0x7fffffff, cx1 = -1, cy0 = 0x7fffffff, cy1 = -1;
         for (int i = tid; i <= a; i += kThreads) {
             const int pc = path[i];
-            sh.pts[i].x = si.grid_origin.x + ((double)(pc % W) + 0.5) * c.cell;
-            sh.pts[i].y = si.grid_origin.y + ((double)(pc / W) + 0.5) * c.cell;
+            const int px = pc % W, py = pc / W;
+            sh.pts[i].x = si.grid_origin.x + ((double)px + 0.5) * c.cell;
+            sh.pts[i].y = si.grid_origin.y + ((double)py + 0.5) * c.cell;
+            cx0 = min(cx0, px); cx1 = max(cx1, px); cy0 = min(cy0, py); cy1 = max(cy1, py);
+        }
+        if (wave < kBoxWaves) {            // DMPP_PATH_POINTS <= 256 points: only the first four waves hold any
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                cx0 = min(cx0, __shfl_xor(cx0, sft, 64)); cx1 = max(cx1, __shfl_xor(cx1, sft, 64));
+                cy0 = min(cy0, __shfl_xor(cy0, sft, 64)); cy1 = max(cy1, __shfl_xor(cy1, sft, 64));
+            }
+            if (lane == 0) { sh.box[wave][0] = cx0; sh.box[wave][1] = cx1; sh.box[wave][2] = cy0; sh.box[wave][3] = cy1; }
         }
     } else {
         T = si.goal;
@@ -94,11 +107,14 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
     double X0 = __builtin_inf(), X1 = -__builtin_inf(), Y0 = __builtin_inf(), Y1 = -__builtin_inf();
     for (int k = 0; k < nl; k++) { X0 = fmin(X0, sh.bx0[k]); X1 = fmax(X1, sh.bx1[k]); Y0 = fmin(Y0, sh.by0[k]); Y1 = fmax(Y1, sh.by1[k]); }
     if (have_path) {
-        // around the centre of the path's first cell, not around the ego: an ego outside the grid is clamped to a border cell
-        const double ext = (double)(a + 2) * c.cell;
-        const int pc0 = path[0];
-        const double px0 = si.grid_origin.x + ((double)(pc0 % W) + 0.5) * c.cell, py0 = si.grid_origin.y + ((double)(pc0 / W) + 0.5) * c.cell;
-        X0 = fmin(X0, px0 - ext); X1 = fmax(X1, px0 + ext); Y0 = fmin(Y0, py0 - ext); Y1 = fmax(Y1, py0 + ext);
+        // the box of the path's own cells (not a box around the ego: an ego outside the grid is clamped to a border cell),
+        // one cell wider - the resampled points lie on the segments between the cell centres
+        int cx0 = 0x7fffffff, cx1 = -1, cy0 = 0x7fffffff, cy1 = -1;
+        for (int w = 0; w < (NW < kBoxWaves ? NW : kBoxWaves); w++) {
+            cx0 = min(cx0, sh.box[w][0]); cx1 = max(cx1, sh.box[w][1]); cy0 = min(cy0, sh.box[w][2]); cy1 = max(cy1, sh.box[w][3]);
+        }
+        X0 = fmin(X0, si.grid_origin.x + ((double)cx0 - 0.5) * c.cell); X1 = fmax(X1, si.grid_origin.x + ((double)cx1 + 1.5) * c.cell);
+        Y0 = fmin(Y0, si.grid_origin.y + ((double)cy0 - 0.5) * c.cell); Y1 = fmax(Y1, si.grid_origin.y + ((double)cy1 + 1.5) * c.cell);
     }
     // the obstacles near the candidates, collected in LDS (kMaxRelObs of them); when more qualify, the scoring loop reads the
     // whole list from HBM instead (the same minimum over the same thresholds either way)
@@ -114,77 +130,143 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
     const bool culled = sh.n_rel <= kMaxRelObs;
     const int n_rel = culled ? sh.n_rel : m;
     GlobalPoint2D* cand = sh.cand[wave];
-    double* seg = sh.seg[wave];
-    for (int k = wave; k < nc; k += NW) {
-        double off = 0;
-        if (k < nl) {
-            const Bezier bz = lattice_curve(k, off);
-            for (int i = lane; i < DMPP_PATH_POINTS; i += DMPP_WAVE) cand[i] = bezier_point(bz, i, DMPP_PATH_POINTS);
+    // The Bezier parameter of a point, and with it the four basis weights, are the same for every lattice candidate: each
+    // lane keeps those of its (<= 4) points (bezier_point's own expressions, so the points come out bit for bit the same).
+    double wb0[4], wb1[4], wb2[4], wb3[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = lane + 64 * q;
+        const double t = (double)i / (double)(DMPP_PATH_POINTS - 1), u = 1 - t;
+        wb0[q] = u * u * u; wb1[q] = 3 * u * u * t; wb2[q] = 3 * u * t * t; wb3[q] = t * t * t;
+    }
+    const double kk2_fenced = 0.001 * 0.001;           // R fenced to 1000
+    // penalty and squared curvature of point i (= p) of the candidate whose points lie in cnd[]
+    auto point_terms = [&](const GlobalPoint2D* cnd, int i, const GlobalPoint2D p, double& pen, double& kk2, bool& hit) {
+        double clear = __builtin_inf();
+        if (culled) {
+            for (int j = 0; j < n_rel; j++) {
+                const double dx = p.x - sh.rx[j], dy = p.y - sh.ry[j];
+                const double d2 = dx * dx + dy * dy;
+                if (d2 > sh.rt2[j]) continue;                 // cannot produce a penalty (no sqrt needed)
+                const double v = sqrt(d2) - sh.rr[j];
+                if (v < clear) clear = v;
+            }
         } else {
-            for (int i = lane; i < DMPP_PATH_POINTS; i += DMPP_WAVE) cand[i] = mean_point(c, sh.pts, sh.cum, a + 1, i, DMPP_PATH_POINTS);
-        }
-        wave_sync();
-        // |P_i - P_{i+1}|: the dis1 / dis2 of the circumradius of neighbouring triples, computed once
-        for (int i = lane; i < DMPP_PATH_POINTS - 1; i += DMPP_WAVE) {
-            const GlobalPoint2D p = cand[i], q = cand[i + 1];
-            seg[i] = sqrt((p.x - q.x) * (p.x - q.x) + (p.y - q.y) * (p.y - q.y));
-        }
-        wave_sync();
-        double pen_acc = 0, k2_acc = 0; int first_hit = DMPP_PATH_POINTS;
-        for (int q = 0; q < 4; q++) {
-            const int i = lane + 64 * q;
-            if (i < DMPP_PATH_POINTS) {
-                const GlobalPoint2D p = cand[i];
-                double clear = __builtin_inf();
-                if (culled) {
-                    for (int j = 0; j < n_rel; j++) {
-                        const double dx = p.x - sh.rx[j], dy = p.y - sh.ry[j];
-                        const double d2 = dx * dx + dy * dy;
-                        if (d2 > sh.rt2[j]) continue;                 // cannot produce a penalty (no sqrt needed)
-                        const double v = sqrt(d2) - sh.rr[j];
-                        if (v < clear) clear = v;
-                    }
-                } else {
-                    for (int j = 0; j < m; j++) {
-                        const double dx = p.x - gobs[j].x, dy = p.y - gobs[j].y;
-                        const double d2 = dx * dx + dy * dy;
-                        const double thr = (double)gobs[j].radius + half_w + c.d_safe;
-                        if (d2 > thr * thr) continue;
-                        const double v = sqrt(d2) - (double)gobs[j].radius;
-                        if (v < clear) clear = v;
-                    }
-                }
-                clear = clear - half_w;
-                double pen;
-                if (clear <= 0) { pen = 1000.0; if (i < first_hit) first_hit = i; }
-                else if (clear < c.d_safe) { const double qq = (c.d_safe - clear) / c.d_safe; pen = qq * qq; }
-                else pen = 0;
-                pen_acc += pen;
-                if (i >= 1 && i <= DMPP_PATH_POINTS - 2) {
-                    // radius3_fenced(P[i-1], P[i], P[i+1]) with dis1 = seg[i-1], dis2 = seg[i]
-                    const GlobalPoint2D pa = cand[i - 1], pf = cand[i + 1];
-                    const double dis1 = seg[i - 1], dis2 = seg[i];
-                    const double dis3 = sqrt((pa.x - pf.x) * (pa.x - pf.x) + (pa.y - pf.y) * (pa.y - pf.y));
-                    const double den = 2 * dis1 * dis2;
-                    // curvature 1 / R with R = 0.5 * dis3 / sinA (fenced to 1000), as one division: sinA / (0.5 * dis3) - the
-                    // oracle's 1 / (0.5 * dis3 / sinA) to an ulp or two (the scores are compared to 1e-6)
-                    double kk = 0.001;
-                    if (den > 0) {
-                        const double cosA = (dis1 * dis1 + dis2 * dis2 - dis3 * dis3) / den;
-                        const double sinA = sqrt(1 - cosA * cosA);
-                        if (sinA >= 0.001) kk = sinA / (0.5 * dis3);
-                    }
-                    k2_acc += kk * kk;
-                }
+            for (int j = 0; j < m; j++) {
+                const double dx = p.x - gobs[j].x, dy = p.y - gobs[j].y;
+                const double d2 = dx * dx + dy * dy;
+                const double thr = (double)gobs[j].radius + half_w + c.d_safe;
+                if (d2 > thr * thr) continue;
+                const double v = sqrt(d2) - (double)gobs[j].radius;
+                if (v < clear) clear = v;
             }
         }
+        clear = clear - half_w;
+        hit = false;
+        if (clear <= 0) { pen = 1000.0; hit = true; }
+        else if (clear < c.d_safe) { const double qq = (c.d_safe - clear) / c.d_safe; pen = qq * qq; }
+        else pen = 0;
+        kk2 = 0;
+        if (i >= 1 && i <= DMPP_PATH_POINTS - 2) {
+            // (1 / R)^2 of the circumradius of (P[i-1], P[i], P[i+1]), R = 0.5 * dis3 / sinA fenced to 1000 - from the
+            // SQUARED side lengths, with one division and no square root:
+            //   cosA = (d1 + d2 - d3) / (2 sqrt(d1 d2))   =>   sinA^2 = (4 d1 d2 - (d1 + d2 - d3)^2) / (4 d1 d2),
+            //   (1 / R)^2 = sinA^2 / (0.25 d3) = (4 d1 d2 - (d1 + d2 - d3)^2) / (d1 d2 d3).
+            // Against the oracle's sqrt / divide chain this differs by rounding only (<= ~1e-9 relative where sinA is at
+            // its fence of 0.001, less elsewhere; the scores are compared to 1e-6).
+            const GlobalPoint2D pa = cnd[i - 1], pf = cnd[i + 1];
+            const double d1 = (pa.x - p.x) * (pa.x - p.x) + (pa.y - p.y) * (pa.y - p.y);
+            const double d2 = (p.x - pf.x) * (p.x - pf.x) + (p.y - pf.y) * (p.y - pf.y);
+            const double d3 = (pa.x - pf.x) * (pa.x - pf.x) + (pa.y - pf.y) * (pa.y - pf.y);
+            const double den2 = 4 * d1 * d2, num = d1 + d2 - d3;
+            const double diff = den2 - num * num;
+            kk2 = kk2_fenced;
+            if (den2 > 0 && diff >= kk2_fenced * den2) kk2 = diff / (d1 * d2 * d3);
+        }
+    };
+    auto publish = [&](int k, double off, double pen_acc, double k2_acc, int first_hit) {      // the whole wave
         const double col = wave_tree_sum(pen_acc), curv = wave_tree_sum(k2_acc);
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) first_hit = min(first_hit, __shfl_xor(first_hit, sft, 64));
         const double prog = (first_hit == DMPP_PATH_POINTS) ? 0.0 : (double)(DMPP_PATH_POINTS - first_hit) / (double)DMPP_PATH_POINTS;
         const double cost = c.w_col * col + c.w_curv * curv + c.w_prog * prog + c.w_off * fabs(off);
         if (lane == 0) { go.cand_col[k] = col; go.cand_curv[k] = curv; go.cand_prog[k] = prog; go.cand_cost[k] = cost; sh.cost[k] = cost; }
+    };
+    // Whole rounds: one candidate per wave.  What is left over (17 candidates on 4 waves leave one) is split by quarter of the
+    // points, one quarter per wave, when the waves suffice (4 * left <= NW); the per-lane partial sums are then added in the
+    // order of the quarters, which is the order one wave would have added them in.
+    const int left = nc % NW, n_whole = (4 * left <= NW) ? nc - left : nc;
+    for (int k = wave; k < n_whole; k += NW) {
+        double off = 0;
+        GlobalPoint2D P[4];
+        if (k < nl) {
+            const Bezier bz = lattice_curve(k, off);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                P[q].x = wb0[q] * bz.x0 + wb1[q] * bz.x1 + wb2[q] * bz.x2 + wb3[q] * bz.x3;
+                P[q].y = wb0[q] * bz.y0 + wb1[q] * bz.y1 + wb2[q] * bz.y2 + wb3[q] * bz.y3;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) P[q] = mean_point(c, sh.pts, sh.cum, a + 1, min(lane + 64 * q, DMPP_PATH_POINTS - 1), DMPP_PATH_POINTS);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (lane + 64 * q < DMPP_PATH_POINTS) cand[lane + 64 * q] = P[q];
         wave_sync();
+        double pen_acc = 0, k2_acc = 0; int first_hit = DMPP_PATH_POINTS;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = lane + 64 * q;
+            if (i < DMPP_PATH_POINTS) {
+                double pen, kk2; bool hit;
+                point_terms(cand, i, P[q], pen, kk2, hit);
+                pen_acc += pen; k2_acc += kk2;
+                if (hit && i < first_hit) first_hit = i;
+            }
+        }
+        publish(k, off, pen_acc, k2_acc, first_hit);
+        wave_sync();
+    }
+    if (n_whole < nc) {
+        struct Part { double pen[DMPP_WAVE], k2[DMPP_WAVE]; int hit[DMPP_WAVE]; };
+        static_assert(sizeof(Part) * NW <= sizeof(GlobalPoint2D) * DMPP_PATH_POINTS * (NW - NW / 4), "the partial sums live in the candidate arrays the left-over candidates do not use");
+        Part* parts = reinterpret_cast<Part*>(&sh.cand[NW / 4][0]);
+        __syncthreads();                                   // every wave is done with its candidate array
+        const bool mine = wave < 4 * left;
+        const int j = wave >> 2, q = wave & 3, k = n_whole + j, i = lane + 64 * q;
+        double off = 0;
+        GlobalPoint2D p = { 0.0, 0.0 };
+        if (mine) {
+            if (k < nl) {
+                const Bezier bz = lattice_curve(k, off);
+                const double b0 = q == 0 ? wb0[0] : q == 1 ? wb0[1] : q == 2 ? wb0[2] : wb0[3], b1 = q == 0 ? wb1[0] : q == 1 ? wb1[1] : q == 2 ? wb1[2] : wb1[3];
+                const double b2 = q == 0 ? wb2[0] : q == 1 ? wb2[1] : q == 2 ? wb2[2] : wb2[3], b3 = q == 0 ? wb3[0] : q == 1 ? wb3[1] : q == 2 ? wb3[2] : wb3[3];
+                p.x = b0 * bz.x0 + b1 * bz.x1 + b2 * bz.x2 + b3 * bz.x3;
+                p.y = b0 * bz.y0 + b1 * bz.y1 + b2 * bz.y2 + b3 * bz.y3;
+            } else p = mean_point(c, sh.pts, sh.cum, a + 1, min(i, DMPP_PATH_POINTS - 1), DMPP_PATH_POINTS);
+            if (i < DMPP_PATH_POINTS) sh.cand[j][i] = p;
+        }
+        __syncthreads();
+        if (mine) {
+            double pen = 0, kk2 = 0; bool hit = false;
+            if (i < DMPP_PATH_POINTS) point_terms(sh.cand[j], i, p, pen, kk2, hit);
+            parts[wave].pen[lane] = pen; parts[wave].k2[lane] = kk2; parts[wave].hit[lane] = hit ? i : DMPP_PATH_POINTS;
+        }
+        __syncthreads();
+        if (wave < left) {                                 // wave j2 = wave adds the quarters of left-over candidate j2 up, in order
+            const int k2i = n_whole + wave;
+            double pen_acc = 0, k2_acc = 0; int first_hit = DMPP_PATH_POINTS;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                if (lane + 64 * qq < DMPP_PATH_POINTS) {
+                    const Part& pt = parts[wave * 4 + qq];
+                    pen_acc += pt.pen[lane]; k2_acc += pt.k2[lane]; first_hit = min(first_hit, pt.hit[lane]);
+                }
+            }
+            double off2 = 0;
+            if (k2i < nl) (void)lattice_curve(k2i, off2);
+            publish(k2i, off2, pen_acc, k2_acc, first_hit);
+        }
     }
     __syncthreads();
     if (tid == 0) {

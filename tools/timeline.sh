@@ -14,7 +14,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ks = [i for i, r in enumerate(rows) if "k_search" in r["Kernel_Name"]]
 i0 = ks[5] if len(ks) > 9 else 0
 t0 = int(rows[i0]["Start_Timestamp"])
-for r in rows[i0:i0 + 40]:
+for r in rows[i0:i0 + 60]:
     name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dmpp::", "")
     print("%-28s q%-3s %9.1f us -> %9.1f us  (%7.1f us)" % (name[:28], r.get("Queue_Id", "?"), (int(r["Start_Timestamp"]) - t0) / 1e3,
           (int(r["End_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))

@@ -35,6 +35,9 @@ struct EvPair { hipEvent_t a, b; int k; };
 // Buffers that a tick's search and scoring touch exist kBuf times, used round-robin ("parity"): up to kBuf searches of
 // consecutive ticks are in flight at once, each on its own stream, and scoring of tick t never holds up the search of t + 1.
 constexpr int kBuf = 3;
+// The obstacle snapshot exists 2 * kBuf times: the front chain of tick t writes its snapshot while the scoring pass of tick
+// t - kBuf still reads its own, so that chain need not wait for that pass (only for the search before it, see pp_plan_tick).
+constexpr int kObs = 2 * kBuf;
 
 }  // namespace
 
@@ -46,7 +49,7 @@ struct pp_planner {
     hipStream_t stream = nullptr;
     // inputs
     SceneIn* d_in = nullptr; GlobalPoint3D* d_lane = nullptr; uint8_t* d_attr = nullptr; bool have_attr = false; GlobalPoint2D* d_ref = nullptr;
-    ObPoint* d_obs = nullptr; ObMotion* d_mot = nullptr; ObPoint* d_obs_now[kBuf] = {};
+    ObPoint* d_obs = nullptr; ObMotion* d_mot = nullptr; ObPoint* d_obs_now[kObs] = {};
     bool have_motion = false;
     // state / outputs
     SceneState* d_state = nullptr; PlanOut* d_plan = nullptr; GridOut* d_gout[kBuf] = {};
@@ -63,17 +66,18 @@ struct pp_planner {
     // search: k_search_lds<kind> with `lds_budget` data words per view in LDS; scenes that need more go to k_search_gbm
     int search_kind = 0; int search_meta_bytes = 0; int lds_budget = 0, lds_budget_max = 0; bool lds_budget_fixed = false, search_force_gbm = false;
     int gbm_lds = 0; int search_slots = 512;
-    int32_t* d_ovf[kBuf] = {}; int32_t* d_need[kBuf] = {}; int32_t* h_need = nullptr;   // h_need: pinned, [kBuf]
-    hipEvent_t ev_need[kBuf] = {}; bool need_pending[kBuf] = {}; int need_seen = 0;
+    int32_t* d_ovf[kBuf] = {}; int32_t* d_need[kBuf] = {}; int32_t* h_need = nullptr;   // h_need: pinned, [kBuf], written by k_score (-1: nothing yet)
+    int need_seen = 0;
     int* d_gridbad = nullptr;
 
     hipStream_t stream_r = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the R kernels run beside the grid engine
     // k_score of tick t runs on its own stream beside the rasterise / search of tick t+1: the obstacle snapshot, the path
     // cells and GridOut are double-buffered by tick parity; ev_score[p] = the last k_score that used the buffers p
-    hipStream_t stream_s = nullptr; hipEvent_t ev_search[kBuf] = {}, ev_score[kBuf] = {};
+    hipStream_t stream_s = nullptr; hipEvent_t ev_search[kBuf] = {}, ev_score[kObs] = {};      // ev_score: per snapshot set
     hipEvent_t ev_raster = nullptr;
-    bool score_recorded[kBuf] = {}, search_recorded[kBuf] = {}, front_recorded = false, front_unjoined = false;
+    bool score_recorded[kObs] = {}, search_recorded[kBuf] = {}, front_recorded = false, front_unjoined = false;
     int parity = 0;              // buffers of the last tick
+    int obs_set = 0;             // obstacle snapshot of the last tick (d_obs_now[obs_set])
     bool score_own_stream = false;   // env DMPP_SCORE_STREAM=1 (measurement knob): k_score on one stream of its own
     int n_cus = 256;
     int pipeline_min = 256;      // batches at least this large run the three chains on three streams (env DMPP_PIPELINE_MIN)
@@ -130,7 +134,7 @@ constexpr int kScoreWideMaxScenes = 128;     // up to here k_score runs 16 waves
 // Decision -> Planning chain (stream order covers the earlier ticks).  No host wait.
 int join_all(pp_planner* h)
 {
-    for (int q = 0; q < kBuf; q++) if (h->score_recorded[q]) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_score[q], 0));
+    for (int q = 0; q < kObs; q++) if (h->score_recorded[q]) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_score[q], 0));
     if (h->front_recorded) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     return PP_OK;
 }
@@ -209,10 +213,9 @@ int setup_grid_launch(pp_planner* h)
             int r = dmalloc(&h->d_ovf[q], (size_t)h->caps.max_scenes); if (r) return r;
             HIP_TRY(hipMemsetAsync(h->d_ovf[q], 0, (size_t)h->caps.max_scenes * sizeof(int32_t), h->stream));
         }
-        if (!h->d_need[q]) { int r = dmalloc(&h->d_need[q], (size_t)1); if (r) return r; }
-        if (!h->ev_need[q]) HIP_TRY(hipEventCreateWithFlags(&h->ev_need[q], hipEventDisableTiming));
+        if (!h->d_need[q]) { int r = dmalloc(&h->d_need[q], (size_t)1); if (r) return r; HIP_TRY(hipMemsetAsync(h->d_need[q], 0, sizeof(int32_t), h->stream)); }
     }
-    if (!h->h_need) { HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_need), kBuf * sizeof(int32_t), hipHostMallocDefault)); for (int q = 0; q < kBuf; q++) h->h_need[q] = 0; }
+    if (!h->h_need) { HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_need), kBuf * sizeof(int32_t), hipHostMallocDefault)); for (int q = 0; q < kBuf; q++) h->h_need[q] = -1; }
     if (!h->d_gridbad) { int r = dmalloc(&h->d_gridbad, (size_t)2); if (r) return r; }
     if (sizeof(dmpp::ScoreShared<16>) > 48u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_score<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(dmpp::ScoreShared<16>));
@@ -285,8 +288,9 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_raster, hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
     for (int q = 0; q < kBuf; q++)
-        if (hipEventCreateWithFlags(&h->ev_search[q], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_score[q], hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
+        if (hipEventCreateWithFlags(&h->ev_search[q], hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
+    for (int q = 0; q < kObs; q++)
+        if (hipEventCreateWithFlags(&h->ev_score[q], hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
     const size_t ns = (size_t)caps->max_scenes;
     if ((r = dmalloc(&h->d_in, ns))) return bail(r);
     if ((r = dmalloc(&h->d_lane, (size_t)caps->max_lane_pts_total))) return bail(r);
@@ -297,7 +301,7 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     if (hipMemsetAsync(h->d_mot, 0, (size_t)(caps->max_obs_total > 0 ? caps->max_obs_total : 1) * sizeof(ObMotion), h->stream) != hipSuccess)
         return bail(fail(PP_ERR_HIP, "memset failed"));     // velocities nobody uploaded are zero, never uninitialised
     if ((r = dmalloc(&h->d_bad, (size_t)1))) return bail(r);
-    for (int q = 0; q < kBuf; q++) if ((r = dmalloc(&h->d_obs_now[q], (size_t)caps->max_obs_total))) return bail(r);
+    for (int q = 0; q < kObs; q++) if ((r = dmalloc(&h->d_obs_now[q], (size_t)caps->max_obs_total))) return bail(r);
     if ((r = dmalloc(&h->d_state, ns))) return bail(r);
     if ((r = dmalloc(&h->d_plan, ns))) return bail(r);
     for (int q = 0; q < kBuf; q++) if ((r = dmalloc(&h->d_gout[q], ns))) return bail(r);
@@ -332,17 +336,18 @@ int pp_destroy(pp_handle h)
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     if (h->stream_s) (void)hipStreamSynchronize(h->stream_s);
+    for (int q = 0; q < kObs; q++) if (h->d_obs_now[q]) (void)hipFree(h->d_obs_now[q]);
     void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_state, h->d_plan,
                      h->d_dec_ref, h->d_grid, h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad, h->d_bad,
                      h->d_gridbad };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int q = 0; q < kBuf; q++)
-        for (void* b : { (void*)h->d_obs_now[q], (void*)h->d_gout[q], (void*)h->d_pinfo[q], (void*)h->d_closed[q], (void*)h->d_order[q], (void*)h->d_path[q],
+        for (void* b : { (void*)h->d_gout[q], (void*)h->d_pinfo[q], (void*)h->d_closed[q], (void*)h->d_order[q], (void*)h->d_path[q],
                          (void*)h->d_gbm[q], (void*)h->d_perm[q], (void*)h->d_cost[q], (void*)h->d_ovf[q], (void*)h->d_need[q] })
             if (b) (void)hipFree(b);
-    for (int q = 0; q < kBuf; q++) { if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]); if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]); }
+    for (int q = 0; q < kBuf; q++) if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]);
+    for (int q = 0; q < kObs; q++) if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]);
     if (h->ev_raster) (void)hipEventDestroy(h->ev_raster);
-    for (int q = 0; q < kBuf; q++) if (h->ev_need[q]) (void)hipEventDestroy(h->ev_need[q]);
     if (h->h_need) (void)hipHostFree(h->h_need);
     if (h->stream_s) (void)hipStreamDestroy(h->stream_s);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -550,12 +555,11 @@ int pp_plan_tick(pp_handle h)
     const bool piped = c.grid_stage && n >= h->pipeline_min;
     if (c.grid_stage && !h->search_force_gbm) {
         // LDS budget of the search (data words per view).  First tick: from the obstacle density; afterwards from what the
-        // densest scene of an earlier tick needed (+ 1/8), read from pinned memory once its copy has landed - never waited for.
+        // densest scene of an earlier tick needed (+ 1/8): the scoring pass behind each search stores it in pinned memory, which
+        // is simply read here - whatever has landed; never waited for.
         if (!h->lds_budget_fixed) {
             int need = -1;
-            for (int q = 0; q < kBuf; q++)
-                if (h->need_pending[q] && hipEventQuery(h->ev_need[q]) == hipSuccess) { h->need_pending[q] = false; need = std::max(need, (int)h->h_need[q]); }
-            (void)hipGetLastError();               // hipEventQuery's "not ready" is not an error
+            for (int q = 0; q < kBuf; q++) need = std::max(need, (int)reinterpret_cast<volatile int32_t*>(h->h_need)[q]);
             int want = h->lds_budget;
             if (need >= 0) {
                 h->need_seen = need;
@@ -583,7 +587,13 @@ int pp_plan_tick(pp_handle h)
     hipStream_t sf = piped ? h->stream_r : h->stream;                  // front chain
     hipStream_t ss = piped ? ((overlap && !h->score_own_stream) ? sm : h->stream_s) : h->stream; // score chain: behind its own search when the searches overlap
     hipStream_t sr = c.grid_stage ? h->stream_r : h->stream;           // Decision + Planning
-    if (h->score_recorded[p]) { HIP_TRY(hipStreamWaitEvent(sf, h->ev_score[p], 0)); HIP_TRY(hipStreamWaitEvent(sm, h->ev_score[p], 0)); }
+    // Buffers p were last used by tick t - kBuf (snapshot set po_b), snapshot set po by tick t - 2 kBuf.  The search waits for
+    // the scoring pass of tick t - kBuf; the front chain only for that tick's SEARCH (its launch order, and so that the front
+    // kernels run in the lull a finished search leaves) and for the scoring pass of tick t - 2 kBuf: it prepares the snapshot
+    // while the scoring pass of tick t - kBuf runs, and the search follows that pass without a hand-over.
+    const int po = (h->obs_set + 1) % kObs, po_b = (po + kBuf) % kObs;
+    if (h->score_recorded[po_b]) HIP_TRY(hipStreamWaitEvent(sm, h->ev_score[po_b], 0));
+    if (h->score_recorded[po]) HIP_TRY(hipStreamWaitEvent(sf, h->ev_score[po], 0));
     if (h->search_recorded[p]) HIP_TRY(hipStreamWaitEvent(sf, h->ev_search[p], 0));
     if (!overlap)                                                      // one search at a time (also after a switch of mode)
         for (int q = 0; q < kBuf; q++) if (q != p && h->search_recorded[q]) HIP_TRY(hipStreamWaitEvent(sm, h->ev_search[q], 0));
@@ -593,7 +603,7 @@ int pp_plan_tick(pp_handle h)
         HIP_TRY(hipEventRecord(h->ev_fork, h->stream)); HIP_TRY(hipStreamWaitEvent(sf, h->ev_fork, 0));
     }
     h->r_on_main = sr == h->stream;
-    ObPoint* obs_now = h->d_obs_now[p];
+    ObPoint* obs_now = h->d_obs_now[po];
     {
         Timed t(h, PP_K_OBSTACLES, sf);
         hipLaunchKernelGGL(dmpp::k_effective_obstacles, dim3(n), dim3(dmpp::kBlock), 0, sf, c, n, h->d_in, h->d_state,
@@ -625,7 +635,6 @@ int pp_plan_tick(pp_handle h)
             hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[p_prev], h->d_perm[p]);
         {
             const int budget = h->search_force_gbm ? 0 : h->lds_budget;
-            HIP_TRY(hipMemsetAsync(h->d_need[p], 0, sizeof(int32_t), sm));
             const bool wide = n <= kScoreWideMaxScenes;       // a few scenes: sixteen waves set each scene up (the latency-bound tick)
             const size_t dyn = std::max((size_t)h->search_meta_bytes + 8 * (size_t)budget, (size_t)h->gbm_lds);
             {
@@ -644,28 +653,24 @@ int pp_plan_tick(pp_handle h)
 #undef DMPP_LAUNCH_SEARCH
                 }
             }
-            if (!h->lds_budget_fixed && !h->search_force_gbm) {       // the words the densest scene needed, for the budget of later ticks (read without waiting)
-                HIP_TRY(hipMemcpyAsync(&h->h_need[p], h->d_need[p], sizeof(int32_t), hipMemcpyDeviceToHost, sm));
-                HIP_TRY(hipEventRecord(h->ev_need[p], sm));
-                h->need_pending[p] = true;
-            }
         }
         h->search_recorded[p] = piped;                   // (one-stream mode: stream order is enough, no events on the latency path)
         if (piped) { HIP_TRY(hipEventRecord(h->ev_search[p], sm)); HIP_TRY(hipStreamWaitEvent(ss, h->ev_search[p], 0)); }
         {
             Timed t(h, PP_K_SCORE, ss);
+            int32_t* need_host = (!h->lds_budget_fixed && !h->search_force_gbm) ? &h->h_need[p] : nullptr;
             if (n <= kScoreWideMaxScenes)     // few scenes: sixteen waves per scene (17 candidates in two rounds)
                 hipLaunchKernelGGL(dmpp::k_score<16>, dim3(n), dim3(16 * DMPP_WAVE), sizeof(dmpp::ScoreShared<16>), ss, c, n, h->d_in, obs_now,
-                                   h->d_path[p], h->d_gout[p]);
+                                   h->d_path[p], h->d_gout[p], h->d_need[p], need_host);
             else
                 hipLaunchKernelGGL(dmpp::k_score<4>, dim3(n), dim3(4 * DMPP_WAVE), sizeof(dmpp::ScoreShared<4>), ss, c, n, h->d_in, obs_now,
-                                   h->d_path[p], h->d_gout[p]);
+                                   h->d_path[p], h->d_gout[p], h->d_need[p], need_host);
         }
-        h->score_recorded[p] = piped;
-        if (piped) HIP_TRY(hipEventRecord(h->ev_score[p], ss));
+        h->score_recorded[po] = piped;
+        if (piped) HIP_TRY(hipEventRecord(h->ev_score[po], ss));
         if (!piped && sr != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));   // one-stream mode: the tick is complete on the handle's stream
     }
-    h->parity = p;
+    h->parity = p; h->obs_set = po;
     HIP_TRY(hipGetLastError());
     return PP_OK;
 }
@@ -724,7 +729,7 @@ int pp_get_grid(pp_handle h, int scene, uint8_t* grid)
     // the column-major view against the row-major one (unless the scene is too dense for one workgroup's LDS).
     HIP_TRY(hipSetDevice(h->device));
     { int r = join_all(h); if (r) return r; }       // the snapshot of the last tick was written on another stream
-    const ObPoint* obs_now = h->d_obs_now[h->parity];
+    const ObPoint* obs_now = h->d_obs_now[h->obs_set];
     int bad[2] = { 0, 0 };
     HIP_TRY(hipMemsetAsync(h->d_gridbad, 0, 2 * sizeof(int), h->stream));
     const int budget = h->search_force_gbm ? 1 : h->lds_budget_max;      // (1 word: nothing fits, the span-by-span path)
@@ -745,7 +750,14 @@ int pp_get_search_info(pp_handle h, int32_t* lds_budget_words, int32_t* need_wor
     if (!h) return fail(PP_ERR_ARG, "null handle");
     if (!h->d_ovf[0]) return fail(PP_ERR_STATE, "handle was created without the grid stage");
     if (lds_budget_words) *lds_budget_words = h->search_force_gbm ? 0 : h->lds_budget;
-    if (need_words) *need_words = h->need_seen;
+    if (need_words) {                      // what the densest scene of the last tick needed (its scoring pass has stored it by now)
+        HIP_TRY(hipSetDevice(h->device));
+        { int r = join_all(h); if (r) return r; }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const int32_t v = reinterpret_cast<volatile int32_t*>(h->h_need)[h->parity];
+        if (v >= 0) h->need_seen = v;
+        *need_words = h->need_seen;
+    }
     if (dense_scenes) {
         std::vector<int32_t> ovf((size_t)std::max(h->n_scenes, 1));
         int r = fetch(h, ovf.data(), h->d_ovf[h->parity], (size_t)h->n_scenes * sizeof(int32_t)); if (r) return r;

@@ -41,15 +41,21 @@ k_order(int n_scenes, const int32_t* __restrict__ cost, int32_t* __restrict__ pe
 }
 
 // ---------------------------------------------------------------------------------------
-// G3 as a kernel of its own (the tick normally scores inside k_search; DMPP_FUSE_SCORE=0 launches this instead).
+// G3.  The kernel follows its tick's search on the stream, so it also hands that search's LDS need to the host (a 4-byte
+// store into pinned memory: no copy command on the stream) and clears the counter for the next search that uses it.
 template <int NW>
 __global__ void __launch_bounds__(NW * DMPP_WAVE)
 k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObPoint* __restrict__ obs_now,
-        const int32_t* __restrict__ paths, GridOut* __restrict__ gout)
+        const int32_t* __restrict__ paths, GridOut* __restrict__ gout, int32_t* __restrict__ need_dev, int32_t* __restrict__ need_host)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     ScoreShared<NW>& sh = *reinterpret_cast<ScoreShared<NW>*>(smem_raw);
     const int scene = blockIdx.x;
+    if (scene == 0 && threadIdx.x == 0 && need_dev) {
+        const int32_t v = *need_dev;
+        *need_dev = 0;
+        if (need_host) *need_host = v;
+    }
     if (scene >= n_scenes) return;
     const SceneIn& si = in[scene];
     GridOut& go = gout[scene];

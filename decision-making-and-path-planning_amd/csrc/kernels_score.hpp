@@ -9,6 +9,7 @@ namespace dmpp {
 // NW waves per scene score the candidates NW at a time: 4 for batches (four scenes per CU), 16 for the few scenes of a
 // latency-bound tick (17 candidates in 2 rounds instead of 5).
 constexpr int kBoxWaves = 4;
+static_assert(DMPP_PATH_POINTS <= kBoxWaves * DMPP_WAVE && DMPP_MAX_LATTICE <= 32, "score_body: lane layouts");
 constexpr int kMaxRelObs = 128;      // culled obstacle list kept in LDS; a scene with more candidates near its paths reads the whole list from HBM
 template <int NW>
 struct ScoreShared {
@@ -16,7 +17,10 @@ struct ScoreShared {
     GlobalPoint2D pts[DMPP_PATH_POINTS];     // grid-path prefix in metres (lookahead_cells+1 <= 200)
     double cum[DMPP_PATH_POINTS];
     double rx[kMaxRelObs], ry[kMaxRelObs], rr[kMaxRelObs], rt2[kMaxRelObs];   // obstacles that can matter: x, y, radius, cutoff^2
-    double bx0[DMPP_MAX_LATTICE], bx1[DMPP_MAX_LATTICE], by0[DMPP_MAX_LATTICE], by1[DMPP_MAX_LATTICE];
+    Bezier bz[DMPP_MAX_LATTICE];             // control points of the lattice candidates
+    double trig[4];                          // cos, sin of the start heading; cos, sin of the terminal heading
+    double bb[4];                            // box of all lattice candidates: x0, x1, y0, y1
+    GlobalPoint2D T;                         // terminal point
     double cost[DMPP_MAX_LATTICE];
     int box[4][4];                           // per wave: min / max cell column and row of the grid-path prefix
     int best, n_rel;
@@ -40,20 +44,13 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
     const int W = c.grid_w;
     const GlobalPoint3D ego = si.loc.globalpoint;
     const bool have_path = (status == DMPP_G_FOUND) && path_len >= 1;
+    const int nl = min(c.n_lattice, DMPP_MAX_LATTICE - 1);
+    const int nc = nl + (have_path ? 1 : 0);
+    const double half_w = 0.5 * c.Vehicle_Width;
     int a = 0;
-    GlobalPoint2D T; double thT;
     if (have_path) {
         a = min(path_len - 1, c.lookahead_cells);
         if (a > DMPP_PATH_POINTS - 1) a = DMPP_PATH_POINTS - 1;
-        const int a0 = max(a - 4, 0);
-        const int pa = path[a], p0 = path[a0];
-        T.x = si.grid_origin.x + ((double)(pa % W) + 0.5) * c.cell;
-        T.y = si.grid_origin.y + ((double)(pa / W) + 0.5) * c.cell;
-        if (a0 == a) thT = ego.dir;
-        else {
-            GlobalPoint2D P0 = { si.grid_origin.x + ((double)(p0 % W) + 0.5) * c.cell, si.grid_origin.y + ((double)(p0 / W) + 0.5) * c.cell };
-            thT = GetRoadAngle(c, P0, T);
-        }
         // the prefix in metres, and the box of its cells (per wave here, combined below): the path candidate lies inside it
         int cx0 = 0x7fffffff, cx1 = -1, cy0 = 0x7fffffff, cy1 = -1;
         for (int i = tid; i <= a; i += kThreads) {
@@ -71,41 +68,63 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
             }
             if (lane == 0) { sh.box[wave][0] = cx0; sh.box[wave][1] = cx1; sh.box[wave][2] = cy0; sh.box[wave][3] = cy1; }
         }
-    } else {
-        T = si.goal;
-        GlobalPoint2D e2 = { ego.x, ego.y };
-        thT = GetRoadAngle(c, e2, si.goal);
+    }
+    // What is the same for every candidate is computed ONCE, by the last wave (the others have the path prefix to convert):
+    // the terminal pose, and the sine and cosine of the start and terminal headings - lane 0 takes the start heading, lane 1
+    // the terminal one, so one pass through sincos yields all four values.
+    if (wave == NW - 1) {
+        GlobalPoint2D T; double thT;
+        if (have_path) {
+            const int a0 = max(a - 4, 0);
+            const int pa = path[a], p0 = path[a0];
+            T.x = si.grid_origin.x + ((double)(pa % W) + 0.5) * c.cell;
+            T.y = si.grid_origin.y + ((double)(pa / W) + 0.5) * c.cell;
+            if (a0 == a) thT = ego.dir;
+            else {
+                GlobalPoint2D P0 = { si.grid_origin.x + ((double)(p0 % W) + 0.5) * c.cell, si.grid_origin.y + ((double)(p0 / W) + 0.5) * c.cell };
+                thT = GetRoadAngle(c, P0, T);
+            }
+        } else {
+            T = si.goal;
+            GlobalPoint2D e2 = { ego.x, ego.y };
+            thT = GetRoadAngle(c, e2, si.goal);
+        }
+        const double ang = (lane == 0 ? ego.dir : thT) * c.PI / 180;
+        double sv, cv;
+        sincos(ang, &sv, &cv);
+        if (lane == 0) { sh.trig[0] = cv; sh.trig[1] = sv; sh.T = T; }
+        if (lane == 1) { sh.trig[2] = cv; sh.trig[3] = sv; }
     }
     __syncthreads();
     if (have_path && wave == 0) wave_cumlen(sh.pts, a + 1, sh.cum, lane);
-    __syncthreads();
-    const int nl = min(c.n_lattice, DMPP_MAX_LATTICE - 1);
-    const int nc = nl + (have_path ? 1 : 0);
-    // the trigonometry is the same for every candidate: start heading, terminal heading
-    const double th0 = ego.dir * c.PI / 180, c0 = cos(th0), s0 = sin(th0);
-    const double th = thT * c.PI / 180, cs = cos(th), sn = sin(th);
-    const double half_w = 0.5 * c.Vehicle_Width;
-    auto lattice_curve = [&](int k, double& off) -> Bezier {        // BezierPlanning(ego -> terminal k), as bezier_setup
-        off = (double)(k - (nl - 1) / 2) * c.lattice_step;
-        Bezier bz;
-        bz.x0 = ego.x; bz.y0 = ego.y; bz.x3 = T.x + off * sn; bz.y3 = T.y + off * (-cs);
-        const double dx = bz.x3 - bz.x0, dy = bz.y3 - bz.y0;
-        const double d = sqrt(dx * dx + dy * dy) / 3;
-        bz.x1 = bz.x0 + d * c0; bz.y1 = bz.y0 + d * s0;
-        bz.x2 = bz.x3 - d * cs; bz.y2 = bz.y3 - d * sn;
-        return bz;
-    };
-    // ---- obstacles that can matter at all: inside the box of every candidate grown by their cutoff.
-    //      A Bezier lies in the hull of its control points; the grid path stays within a+1 cells of its first cell.
-    if (tid < nl) {
-        double off; const Bezier bz = lattice_curve(tid, off);
-        sh.bx0[tid] = fmin(fmin(bz.x0, bz.x1), fmin(bz.x2, bz.x3)); sh.bx1[tid] = fmax(fmax(bz.x0, bz.x1), fmax(bz.x2, bz.x3));
-        sh.by0[tid] = fmin(fmin(bz.y0, bz.y1), fmin(bz.y2, bz.y3)); sh.by1[tid] = fmax(fmax(bz.y0, bz.y1), fmax(bz.y2, bz.y3));
+    // ---- the lattice: candidate k is the cubic Bezier of BezierPlanning(ego -> terminal k) (as bezier_setup); lane k of the
+    //      last wave sets it up for every wave to read.  Obstacles that can matter at all lie inside the box of every candidate
+    //      grown by their cutoff: a Bezier lies in the hull of its control points. ----
+    if (wave == NW - 1) {
+        double X0 = __builtin_inf(), X1 = -__builtin_inf(), Y0 = __builtin_inf(), Y1 = -__builtin_inf();
+        if (lane < nl) {
+            const double c0 = sh.trig[0], s0 = sh.trig[1], cs = sh.trig[2], sn = sh.trig[3];
+            const GlobalPoint2D T = sh.T;
+            const double off = (double)(lane - (nl - 1) / 2) * c.lattice_step;
+            Bezier bz;
+            bz.x0 = ego.x; bz.y0 = ego.y; bz.x3 = T.x + off * sn; bz.y3 = T.y + off * (-cs);
+            const double dx = bz.x3 - bz.x0, dy = bz.y3 - bz.y0;
+            const double d = sqrt(dx * dx + dy * dy) / 3;
+            bz.x1 = bz.x0 + d * c0; bz.y1 = bz.y0 + d * s0;
+            bz.x2 = bz.x3 - d * cs; bz.y2 = bz.y3 - d * sn;
+            sh.bz[lane] = bz;
+            X0 = fmin(fmin(bz.x0, bz.x1), fmin(bz.x2, bz.x3)); X1 = fmax(fmax(bz.x0, bz.x1), fmax(bz.x2, bz.x3));
+            Y0 = fmin(fmin(bz.y0, bz.y1), fmin(bz.y2, bz.y3)); Y1 = fmax(fmax(bz.y0, bz.y1), fmax(bz.y2, bz.y3));
+        }
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) {          // DMPP_MAX_LATTICE <= 32 candidates: lanes 0..31
+            X0 = fmin(X0, shfl_xor_f64(X0, sft)); X1 = fmax(X1, shfl_xor_f64(X1, sft));
+            Y0 = fmin(Y0, shfl_xor_f64(Y0, sft)); Y1 = fmax(Y1, shfl_xor_f64(Y1, sft));
+        }
+        if (lane == 0) { sh.bb[0] = X0; sh.bb[1] = X1; sh.bb[2] = Y0; sh.bb[3] = Y1; sh.n_rel = 0; }
     }
-    if (tid == 0) sh.n_rel = 0;
     __syncthreads();
-    double X0 = __builtin_inf(), X1 = -__builtin_inf(), Y0 = __builtin_inf(), Y1 = -__builtin_inf();
-    for (int k = 0; k < nl; k++) { X0 = fmin(X0, sh.bx0[k]); X1 = fmax(X1, sh.bx1[k]); Y0 = fmin(Y0, sh.by0[k]); Y1 = fmax(Y1, sh.by1[k]); }
+    double X0 = sh.bb[0], X1 = sh.bb[1], Y0 = sh.bb[2], Y1 = sh.bb[3];
     if (have_path) {
         // the box of the path's own cells (not a box around the ego: an ego outside the grid is clamped to a border cell),
         // one cell wider - the resampled points lie on the segments between the cell centres
@@ -200,7 +219,8 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
         double off = 0;
         GlobalPoint2D P[4];
         if (k < nl) {
-            const Bezier bz = lattice_curve(k, off);
+            const Bezier bz = sh.bz[k];
+            off = (double)(k - (nl - 1) / 2) * c.lattice_step;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 P[q].x = wb0[q] * bz.x0 + wb1[q] * bz.x1 + wb2[q] * bz.x2 + wb3[q] * bz.x3;
@@ -234,11 +254,10 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
         __syncthreads();                                   // every wave is done with its candidate array
         const bool mine = wave < 4 * left;
         const int j = wave >> 2, q = wave & 3, k = n_whole + j, i = lane + 64 * q;
-        double off = 0;
         GlobalPoint2D p = { 0.0, 0.0 };
         if (mine) {
             if (k < nl) {
-                const Bezier bz = lattice_curve(k, off);
+                const Bezier bz = sh.bz[k];
                 const double b0 = q == 0 ? wb0[0] : q == 1 ? wb0[1] : q == 2 ? wb0[2] : wb0[3], b1 = q == 0 ? wb1[0] : q == 1 ? wb1[1] : q == 2 ? wb1[2] : wb1[3];
                 const double b2 = q == 0 ? wb2[0] : q == 1 ? wb2[1] : q == 2 ? wb2[2] : wb2[3], b3 = q == 0 ? wb3[0] : q == 1 ? wb3[1] : q == 2 ? wb3[2] : wb3[3];
                 p.x = b0 * bz.x0 + b1 * bz.x1 + b2 * bz.x2 + b3 * bz.x3;
@@ -263,8 +282,7 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
                     pen_acc += pt.pen[lane]; k2_acc += pt.k2[lane]; first_hit = min(first_hit, pt.hit[lane]);
                 }
             }
-            double off2 = 0;
-            if (k2i < nl) (void)lattice_curve(k2i, off2);
+            const double off2 = k2i < nl ? (double)(k2i - (nl - 1) / 2) * c.lattice_step : 0.0;
             publish(k2i, off2, pen_acc, k2_acc, first_hit);
         }
     }
@@ -281,8 +299,7 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
         if (tid < DMPP_PATH_POINTS) {
             GlobalPoint2D p = { 0.0, 0.0 };                 // no candidate at all (n_lattice = 0 and no grid path): zeros
             if (k < nl) {
-                double off; const Bezier bz = lattice_curve(k, off);
-                p = bezier_point(bz, tid, DMPP_PATH_POINTS);
+                p = bezier_point(sh.bz[k], tid, DMPP_PATH_POINTS);
             } else if (nc > 0) p = mean_point(c, sh.pts, sh.cum, a + 1, tid, DMPP_PATH_POINTS);
             go.best_path[tid] = p;
         }

@@ -98,12 +98,15 @@ struct SparseView {
 
     __device__ __forceinline__ LineM<M> line(int l) const
     {
-        LineM<M> r; r.mask = 0; r.off = kLineOutside;
-        if ((unsigned)l < (unsigned)NL) {
-            if constexpr (K == 0) { const uint32_t v = ((DMPP_LDS const uint32_t*)meta)[l]; r.mask = v & 0xFFFFu; r.off = v >> 16; }
-            else if constexpr (K == 1) { r.mask = ((DMPP_LDS const uint32_t*)meta)[2 * l]; r.off = ((DMPP_LDS const uint32_t*)meta)[2 * l + 1]; }
-            else { r.mask = ((DMPP_LDS const uint64_t*)meta)[l]; r.off = off2[l]; }
-        }
+        // branch-free (an unconditional read of line 0 for a line outside the grid, then selects): reads of several lines
+        // issue together and share one wait
+        LineM<M> r;
+        const bool in = (unsigned)l < (unsigned)NL;
+        const int li = in ? l : 0;
+        if constexpr (K == 0) { const uint32_t v = ((DMPP_LDS const uint32_t*)meta)[li]; r.mask = v & 0xFFFFu; r.off = v >> 16; }
+        else if constexpr (K == 1) { r.mask = ((DMPP_LDS const uint32_t*)meta)[2 * li]; r.off = ((DMPP_LDS const uint32_t*)meta)[2 * li + 1]; }
+        else { r.mask = ((DMPP_LDS const uint64_t*)meta)[li]; r.off = off2[li]; }
+        if (!in) { r.mask = 0; r.off = kLineOutside; }
         return r;
     }
     __device__ __forceinline__ uint32_t word(const LineM<M>& m, int w) const
@@ -165,15 +168,13 @@ struct DenseView {
 template <class V>
 __device__ __forceinline__ bool cell_blocked(const V& rowv, int x, int y)
 {
-    if ((unsigned)x >= (unsigned)(rowv.LW << 5)) return true;
     const auto m = rowv.line(y);
-    return (rowv.word(m, x >> 5) >> (x & 31)) & 1u;
+    return (rowv.word(m, x >> 5) >> (x & 31)) & 1u;          // word(): all ones beyond either end of the line
 }
 template <class V, class L>
 __device__ __forceinline__ bool cell_blocked_m(const V& v, const L& m, int p)       // cell at position p of a line already described by m
 {
-    if ((unsigned)p >= (unsigned)(v.LW << 5)) return true;
-    return (v.word(m, p >> 5) >> (p & 31)) & 1u;
+    return (v.word(m, p >> 5) >> (p & 31)) & 1u;             // word(): all ones beyond either end of the line
 }
 
 // run = cells travelled from `pos` along `line` in direction sgn to the first stop (blocked | forced | goal);
@@ -188,42 +189,39 @@ __device__ __forceinline__ int jump_lane(const V& vw, const L& m0, const L& mP, 
     using M = typename V::M;
     int run = 0;
     bool go = active && (unsigned)line < (unsigned)vw.NL && (unsigned)pos < (unsigned)(vw.LW << 5);
+    const bool fwd = sgn > 0;
     const int w0 = pos >> 5;
+    const bool goal_line = gline == line;
     M cand = 0;
     if (go) {
         cand = m0.mask | mP.mask | mM.mask;
-        if (gline == line) cand |= (M)1 << (gpos >> 5);
-        cand &= sgn > 0 ? (M)~((((M)1) << w0) - (M)1) : (M)((((M)2) << w0) - (M)1);     // the start word and everything ahead of it
+        if (goal_line) cand |= (M)1 << (gpos >> 5);
+        cand &= fwd ? (M)~((((M)1) << w0) - (M)1) : (M)((((M)2) << w0) - (M)1);     // the start word and everything ahead of it
         go = cand != 0;
     }
+    // Both directions run the same code: a lane that travels towards lower positions bit-reverses the words it reads, so that
+    // "the next cell" is always the next higher bit and the first stop the lowest set bit.  All five reads of a visited word
+    // (the line, its two neighbours, and the neighbours' next word along the travel, which only matters for the last cell of
+    // the word) are issued together, unconditionally: one wait per visited word, no branches around the reads.
+    const int bp = fwd ? (pos & 31) : 31 - (pos & 31);                     // the start cell in travel order
+    const uint32_t ahead = (bp == 31) ? 0u : ~((2u << bp) - 1u);           // cells strictly ahead of it, in travel order
+    const int gb = fwd ? (gpos & 31) : 31 - (gpos & 31);
     for (int it = 0; it <= vw.LW; it++) {
         if (!__ballot(go)) break;
         if (iters) ++*iters;
+        const int wi = !go ? w0 : (fwd ? lsb_m(cand) : msb_m(cand));
+        cand &= (M)~(((M)1) << wi);
+        const int wn = wi + sgn;
+        uint32_t B0 = vw.word(m0, wi), P = vw.word(mP, wi), Mi = vw.word(mM, wi), Pw = vw.word(mP, wn), Mw = vw.word(mM, wn);
+        if (!fwd) { B0 = __brev(B0); P = __brev(P); Mi = __brev(Mi); Pw = __brev(Pw); Mw = __brev(Mw); }
+        const uint32_t Pn = (P >> 1) | (Pw << 31), Mn = (Mi >> 1) | (Mw << 31);
+        uint32_t stop = B0 | (P & ~Pn) | (Mi & ~Mn);
+        if (goal_line && (gpos >> 5) == wi) stop |= 1u << gb;
+        if (wi == w0) stop &= ahead;
         if (go) {
-            const int wi = sgn > 0 ? lsb_m(cand) : msb_m(cand);
-            cand &= (M)~(((M)1) << wi);
-            const uint32_t B0 = vw.word(m0, wi);
-            const uint32_t P = vw.word(mP, wi), Mi = vw.word(mM, wi);
-            // the neighbour's next word along the travel only matters for the last cell of this word, and only when the
-            // neighbour is blocked there
-            uint32_t Pn, Mn;
-            if (sgn > 0) {
-                const uint32_t Pw = (P >> 31) ? vw.word(mP, wi + 1) : 0u, Mw = (Mi >> 31) ? vw.word(mM, wi + 1) : 0u;
-                Pn = (P >> 1) | (Pw << 31); Mn = (Mi >> 1) | (Mw << 31);
-            } else {
-                const uint32_t Pw = (P & 1u) ? vw.word(mP, wi - 1) : 0u, Mw = (Mi & 1u) ? vw.word(mM, wi - 1) : 0u;
-                Pn = (P << 1) | (Pw >> 31); Mn = (Mi << 1) | (Mw >> 31);
-            }
-            uint32_t stop = B0 | (P & ~Pn) | (Mi & ~Mn);
-            if (gline == line && (gpos >> 5) == wi) stop |= 1u << (gpos & 31);
-            if (wi == w0) {                                  // only the cells strictly ahead of the start
-                const int bp = pos & 31;
-                if (sgn > 0) stop &= (bp == 31) ? 0u : ~((2u << bp) - 1u);
-                else         stop &= (1u << bp) - 1u;
-            }
             if (stop) {
-                const int bit = sgn > 0 ? (__ffs((int)stop) - 1) : (31 - __clz((int)stop));
-                if (!((B0 >> bit) & 1u)) { const int np = (wi << 5) + bit; run = sgn > 0 ? np - pos : pos - np; }
+                const int bit = __ffs((int)stop) - 1;
+                if (!((B0 >> bit) & 1u)) { const int np = (wi << 5) + (fwd ? bit : 31 - bit); run = fwd ? np - pos : pos - np; }
                 go = false;
             } else if (cand == 0) go = false;                // free all the way to the edge of the grid: no jump point
         }
@@ -642,6 +640,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
             const bool side_blk = cell_blocked(Vrow, x + px, y + py);
             diag0 = !t_blk && (plain || (sided && side_blk));
         }
+        DBG_MARK(11)
         // ---- closed?  duplicates inside the batch: the earlier one wins; then the closed set (lanes with s == 0) ----
         bool valid = have && s == 0;
         {
@@ -720,6 +719,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
         if (want_jump || want_diag) L.job[want_diag ? my_dc : kMaxDiag + my_sj] = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24);
         wave_order();
         const int n_rounds_j = (n_sj | n_dc) ? max(1, (n_dc + 3) >> 2) : 0;
+        DBG_MARK(7)
         for (int rnd = 0; rnd < n_rounds_j; rnd++) {
             // -- cell tests: lanes 0..31 = (job aj, cell ak) of this round --
             const int dca = rnd * 4 + aj;
@@ -742,6 +742,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
             }
             const V vw = hv ? Vcol : Vrow;                                     // by value: per-lane field selects
             const auto m0 = vw.line(b_act ? jl : -1), mP = vw.line(b_act ? jl + 1 : -1), mM = vw.line(b_act ? jl - 1 : -1);
+            DBG_MARK(8)
             bool cblk = false, cstop = false;
             {
                 const int ox = (int)(Ja & 0xFFFu), oy = (int)((Ja >> 12) & 0xFFFu), os = (int)(Ja >> 24);
@@ -755,11 +756,13 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
                 cstop = a_act & (b0 | ((cx == gx) & (cy == gy)) | forced);
                 cblk = b0 & a_act;
             }
+            DBG_MARK(9)
 #ifdef DMPP_DEBUG_SEARCH
             const int r = jump_lane(vw, m0, mP, mM, b_act, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx, &dbg_c[2]);
 #else
             const int r = jump_lane(vw, m0, mP, mM, b_act, jl, jp, jsg, hv ? gx : gy, hv ? gy : gx);
 #endif
+            DBG_MARK(10)
             // -- results.  Diagonal job j of the round: the first cell k with a cell-test stop (bits j*8 + k-1 of the test ballot)
             //    or a scan hit (bits j*7 + k-1 of the horizontal / 28 + j*7 + k-1 of the vertical half of the scan ballot) ends
             //    the jump; every owner lane works its own job out of the three wave-uniform masks. --
@@ -971,6 +974,7 @@ __device__ __forceinline__ void publish_debug(int32_t* path, int max_path, const
     dbg[10] = (int)(t[6] >> 4); dbg[11] = (int)((t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6]) >> 4); dbg[12] = (int)(t_setup >> 4); dbg[13] = (int)(t_total >> 4);
     dbg[14] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
     dbg[15] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+    for (int i = 7; i < 16; i++) path[max_path - 64 + i] = (int)(t[i] >> 4);
 }
 #endif
 
@@ -1060,7 +1064,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t
     uint16_t* pin = pinfo + (size_t)scene * N;
     int32_t* order = orders ? orders + (size_t)scene * order_cap : nullptr;
 #ifdef DMPP_DEBUG_SEARCH
-    long long dbg_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int dbg_c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    long long dbg_t[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; int dbg_c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (!goal_blocked) R = dense ? search_core(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, lane, dbg_t, dbg_c)
                                  : search_core(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, lane, dbg_t, dbg_c);
     if (lane == 0) {

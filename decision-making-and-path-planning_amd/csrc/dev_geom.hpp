@@ -28,6 +28,9 @@ __device__ __forceinline__ void wave_order()
     __builtin_amdgcn_wave_barrier();
 }
 
+// __ballot() takes an int: a bool predicate would be materialised as 0 / 1 and compared again; this keeps it a lane mask
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask)

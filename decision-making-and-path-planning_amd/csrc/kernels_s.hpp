@@ -207,7 +207,7 @@ __device__ __forceinline__ int jump_lane(const V& vw, const L& m0, const L& mP, 
     const uint32_t ahead = (bp == 31) ? 0u : ~((2u << bp) - 1u);           // cells strictly ahead of it, in travel order
     const int gb = fwd ? (gpos & 31) : 31 - (gpos & 31);
     for (int it = 0; it <= vw.LW; it++) {
-        if (!__ballot(go)) break;
+        if (!wave_ballot(go)) break;
         if (iters) ++*iters;
         const int wi = !go ? w0 : (fwd ? lsb_m(cand) : msb_m(cand));
         cand &= (M)~(((M)1) << wi);
@@ -354,7 +354,7 @@ __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const Scen
             icx = (int)floor((f.ox - origin.x) / cell);
             icy = (int)floor((f.oy - origin.y) / cell);
         }
-        const unsigned long long anym = __ballot(j < m && f.ix1 >= f.ix0 && f.iy1 >= f.iy0);
+        const unsigned long long anym = wave_ballot(j < m && f.ix1 >= f.ix0 && f.iy1 >= f.iy0);
         const int left = m - base - wv;
         const int cnt = left <= 0 ? 0 : min(DMPP_WAVE, (left + SW - 1) / SW);
         for (int q = 0; q < cnt; q++) {
@@ -516,7 +516,7 @@ __device__ __forceinline__ int squeeze_open(SearchLds& L, int n_open, int lane)
         uint32_t f2 = 0xFFFFu, ee = 0; uint16_t rr = 0;
         if (i < n_open) { f2 = L.o_f2[i]; ee = L.o_ent[i]; rr = L.o_run[i]; }
         const bool alive = f2 != 0xFFFFu;
-        const unsigned long long am = __ballot(alive);
+        const unsigned long long am = wave_ballot(alive);
         wave_order();
         if (alive) {
             const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
@@ -594,23 +594,25 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
         const uint32_t fmin2 = wave_min_u32(min(min(min(v0, v1), min(v2, v3)), min(min(v4, v5), min(v6, v7))));
         if (fmin2 == 0xFFFFu) { status = DMPP_G_INTERNAL; break; }
         const int f = (int)fmin2 << 1;
-        int nt = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+        // the (<= 4) slots taken, 16 bits each, first taken in the low bits (scalar: the tie masks are wave-uniform)
+        int nt = 0; unsigned long long sel = 0;
 #define DMPP_TAKE(vreg, base)                                                                        \
         {                                                                                            \
-            unsigned long long tm = __ballot((vreg) == fmin2);                                       \
+            unsigned long long tm = wave_ballot((vreg) == fmin2);                                    \
             while (tm && nt < DMPP_JPS_BATCH) {                                                      \
                 const int b = 63 - __clzll((long long)tm);                                           \
                 tm &= ~(1ull << b);                                                                  \
-                const int idx = (base) + b;                                                          \
-                if (nt == 0) i0 = idx; else if (nt == 1) i1 = idx; else if (nt == 2) i2 = idx; else i3 = idx; \
+                sel |= (unsigned long long)((base) + b) << (16 * nt);                                \
                 nt++;                                                                                \
             }                                                                                        \
         }
         if (upper) { DMPP_TAKE(v7, 448) DMPP_TAKE(v6, 384) DMPP_TAKE(v5, 320) DMPP_TAKE(v4, 256) }
         DMPP_TAKE(v3, 192) DMPP_TAKE(v2, 128) DMPP_TAKE(v1, 64) DMPP_TAKE(v0, 0)
 #undef DMPP_TAKE
+        static_assert(DMPP_JPS_BATCH == 4 && kOpenCap <= 65536, "four 16-bit slot numbers in one 64-bit scalar");
         // every (node, s) lane reads its node's entry itself (a broadcast read): no cross-lane traffic afterwards
-        const int myi = node == 0 ? i0 : node == 1 ? i1 : node == 2 ? i2 : i3;
+        const int i0 = (int)(sel & 0xFFFFu);
+        const int myi = (int)((sel >> (16 * node)) & 0xFFFFu);
         const bool have = lane < 32 && node < nt;
         const uint32_t e = L.o_ent[myi]; const int run_in = L.o_run[myi];
         wave_order();
@@ -685,14 +687,14 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
         }
         // node mask from the s == 0 lanes (bits 0, 8, 16, 24 of a ballot -> bits 0..3)
         auto nodes_of = [](unsigned long long bm) { const unsigned b = (unsigned)bm; return (b & 1u) | ((b >> 7) & 2u) | ((b >> 14) & 4u) | ((b >> 21) & 8u); };
-        unsigned vm = nodes_of(__ballot(valid));
+        unsigned vm = nodes_of(wave_ballot(valid));
         {   // the goal, or the entry that reaches the expansion limit, ends the search at once
             const int nvb = __popc(vm & ((1u << node) - 1u));
-            const unsigned stop = nodes_of(__ballot(valid && (cell == goal || n_exp + nvb + 1 >= c.max_expansions)));
+            const unsigned stop = nodes_of(wave_ballot(valid && (cell == goal || n_exp + nvb + 1 >= c.max_expansions)));
             if (stop) {
                 const int last = __ffs((int)stop) - 1;
                 if (node > last) valid = false;
-                vm = nodes_of(__ballot(valid));
+                vm = nodes_of(wave_ballot(valid));
             }
         }
         if (valid) {
@@ -703,7 +705,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
         }
         if (vm && f > fmax) { fmax = f; n_rounds++; }
         n_exp += __popc(vm);
-        if (__ballot(valid && cell == goal)) { status = DMPP_G_FOUND; path_cost = f; break; }
+        if (wave_ballot(valid && cell == goal)) { status = DMPP_G_FOUND; path_cost = f; break; }
         if (n_exp >= c.max_expansions) { status = DMPP_G_LIMIT; break; }
         if (vm == 0) continue;
         DBG_MARK(1)
@@ -713,7 +715,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
         DBG_MARK(2)
         // ---- jumps.  The successor lanes post their jobs (x | y << 12 | s << 24) in LDS, diagonal ones in slots 0..15 and
         //      straight ones in 16..23, in lane order; the scan lanes and the cell-test lanes pick them up. ----
-        const unsigned smask = (unsigned)__ballot(want_jump), dmask = (unsigned)__ballot(want_diag);
+        const unsigned smask = (unsigned)wave_ballot(want_jump), dmask = (unsigned)wave_ballot(want_diag);
         const int n_sj = __popc(smask), n_dc = __popc(dmask);
         const int my_sj = __popc(smask & ((1u << (lane & 31)) - 1u)), my_dc = __popc(dmask & ((1u << (lane & 31)) - 1u));
         if (want_jump || want_diag) L.job[want_diag ? my_dc : kMaxDiag + my_sj] = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24);
@@ -741,19 +743,20 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
                 }
             }
             const V vw = hv ? Vcol : Vrow;                                     // by value: per-lane field selects
+            // the six line descriptors of the round (three for the scan, three for the cell test) are read together: one wait
+            const int aox = (int)(Ja & 0xFFFu), aoy = (int)((Ja >> 12) & 0xFFFu), aos = (int)(Ja >> 24);
+            const int aodx = (aos == 1 || aos == 7) ? 1 : -1, aody = (aos == 1 || aos == 3) ? 1 : -1;
+            const int acx = aox + ak * aodx, acy = aoy + ak * aody;
             const auto m0 = vw.line(b_act ? jl : -1), mP = vw.line(b_act ? jl + 1 : -1), mM = vw.line(b_act ? jl - 1 : -1);
+            const auto r0 = Vrow.line(a_act ? acy : -1), ra = Vrow.line(a_act ? acy + aody : -1), rb = Vrow.line(a_act ? acy - aody : -1);
             DBG_MARK(8)
             bool cblk = false, cstop = false;
             {
-                const int ox = (int)(Ja & 0xFFFu), oy = (int)((Ja >> 12) & 0xFFFu), os = (int)(Ja >> 24);
-                const int odx = (os == 1 || os == 7) ? 1 : -1, ody = (os == 1 || os == 3) ? 1 : -1;
-                const int cx = ox + ak * odx, cy = oy + ak * ody;
-                const auto r0 = Vrow.line(a_act ? cy : -1), ra = Vrow.line(a_act ? cy + ody : -1), rb = Vrow.line(a_act ? cy - ody : -1);
                 // five independent reads, combined without short-circuits: one wait for all of them, no branches
-                const bool b0 = cell_blocked_m(Vrow, r0, cx), b1 = cell_blocked_m(Vrow, r0, cx - odx), b2 = cell_blocked_m(Vrow, ra, cx - odx);
-                const bool b3 = cell_blocked_m(Vrow, rb, cx), b4 = cell_blocked_m(Vrow, rb, cx + odx);
+                const bool b0 = cell_blocked_m(Vrow, r0, acx), b1 = cell_blocked_m(Vrow, r0, acx - aodx), b2 = cell_blocked_m(Vrow, ra, acx - aodx);
+                const bool b3 = cell_blocked_m(Vrow, rb, acx), b4 = cell_blocked_m(Vrow, rb, acx + aodx);
                 const bool forced = (b1 & !b2) | (b3 & !b4);
-                cstop = a_act & (b0 | ((cx == gx) & (cy == gy)) | forced);
+                cstop = a_act & (b0 | ((acx == gx) & (acy == gy)) | forced);
                 cblk = b0 & a_act;
             }
             DBG_MARK(9)
@@ -766,7 +769,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
             // -- results.  Diagonal job j of the round: the first cell k with a cell-test stop (bits j*8 + k-1 of the test ballot)
             //    or a scan hit (bits j*7 + k-1 of the horizontal / 28 + j*7 + k-1 of the vertical half of the scan ballot) ends
             //    the jump; every owner lane works its own job out of the three wave-uniform masks. --
-            const unsigned long long am = __ballot(cstop), kb = __ballot(cblk), sb = __ballot(is_dscan && r > 0);
+            const unsigned long long am = wave_ballot(cstop), kb = wave_ballot(cblk), sb = wave_ballot(is_dscan && r > 0);
             if (want_diag && (my_dc >> 2) == rnd) {
                 const int j = my_dc & 3;
                 const unsigned ta = (unsigned)(am >> (8 * j)) & 0xFFu, tk = (unsigned)(kb >> (8 * j)) & 0xFFu;
@@ -785,14 +788,14 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
 #endif
         // ---- push in batch order, then direction order ----
         const bool push = run > 0;
-        const unsigned pm = (unsigned)__ballot(push);
+        const unsigned pm = (unsigned)wave_ballot(push);
         const int cnt = __popc(pm);
         if (cnt) {
             const int nx = x + run * sdx, ny = y + run * sdy;
             const int fn = gcur + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
             // f/2 lives in 16 bits (0xFFFF = dead slot): a push at or beyond DMPP_F_LIMIT ends the search.  The oracle tests
             // each push in turn, the range before the capacity: the earlier of the two failing pushes decides the status.
-            const unsigned rm = (unsigned)__ballot(push && fn >= DMPP_F_LIMIT);
+            const unsigned rm = (unsigned)wave_ballot(push && fn >= DMPP_F_LIMIT);
             if (rm || live + cnt > cap) {
                 const int k_range = rm ? __popc(pm & ((1u << (__ffs((int)rm) - 1)) - 1u)) : 0x7FFFFFFF;
                 const int k_cap = live + cnt > cap ? cap - live : 0x7FFFFFFF;
@@ -889,7 +892,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
                 // straight runs: the whole wave writes one run together
                 constexpr int kLongRun = 12;
                 if (rn && rn <= kLongRun) { int idx = idx0; for (int r = 0; r < rn && idx < keep; r++, idx++) path[keep - 1 - idx] = ec - r * step; }
-                unsigned long long lm = __ballot(rn > kLongRun);
+                unsigned long long lm = wave_ballot(rn > kLongRun);
                 while (lm) {
                     const int src = __ffsll((long long)lm) - 1;
                     lm &= lm - 1;

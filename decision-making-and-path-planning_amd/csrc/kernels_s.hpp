@@ -652,16 +652,22 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
         }
         uint32_t my_slot = 0;
         if (n_exp + DMPP_JPS_BATCH <= kClosedMax) {
-            if (valid) {
-                const uint32_t keyc = (uint32_t)cell + 1u;
-                uint32_t hh = ((uint32_t)cell * 2654435761u) >> (32 - kClosedLog);
-                for (int probe = 0; probe < kClosedTab; probe++) {
-                    const uint32_t old = atomicCAS(&L.c_tab[hh], 0u, keyc);
-                    if (old == 0u) { L.c_info[hh] = (uint16_t)(d | (run_in << 4)); L.c_seq[hh] = 0xFFFFu; my_slot = hh; break; }   // inserted: was open
-                    if (old == keyc) { valid = false; break; }            // already closed
+            // first probe in straight-line code (nearly always the last); a collision chain is walked in a wave-uniform loop
+            const uint32_t keyc = (uint32_t)cell + 1u;
+            uint32_t hh = ((uint32_t)cell * 2654435761u) >> (32 - kClosedLog);
+            uint32_t old = 0u;
+            if (valid) old = atomicCAS(&L.c_tab[hh], 0u, keyc);
+            if (old == keyc) valid = false;                               // already closed
+            bool collide = valid && old != 0u;
+            for (int probe = 1; probe < kClosedTab && wave_ballot(collide); probe++) {
+                if (collide) {
                     hh = (hh + 1) & (kClosedTab - 1);
+                    old = atomicCAS(&L.c_tab[hh], 0u, keyc);
+                    if (old == keyc) valid = false;
+                    collide = old != 0u && old != keyc;
                 }
             }
+            my_slot = hh;                                                 // valid: inserted here (its direction | run and number follow below)
         } else {
             if (hash_complete) {
                 // ---- spill: this scene outgrows the LDS hash.  Its bit set in HBM is zeroed now, not at launch (most scenes
@@ -685,6 +691,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
                 if ((old >> (cell & 31)) & 1u) valid = false;
             }
         }
+        const bool inserted = valid;                 // (while the LDS hash is complete: valid <=> the cell was inserted just now)
         // node mask from the s == 0 lanes (bits 0, 8, 16, 24 of a ballot -> bits 0..3)
         auto nodes_of = [](unsigned long long bm) { const unsigned b = (unsigned)bm; return (b & 1u) | ((b >> 7) & 2u) | ((b >> 14) & 4u) | ((b >> 21) & 8u); };
         unsigned vm = nodes_of(wave_ballot(valid));
@@ -697,11 +704,15 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
                 vm = nodes_of(wave_ballot(valid));
             }
         }
-        if (valid) {
+        {
             const int seq = n_exp + __popc(vm & ((1u << node) - 1u));
-            if (hash_complete) L.c_seq[my_slot] = (uint16_t)seq;      // the digest is summed from the hash at the end: 64 lanes at once, off the chain of steps
-            else { pin[cell] = (uint16_t)(d | (run_in << 4)); digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell); }
-            if (order && seq < order_cap) order[seq] = cell;
+            // the hash entry of every cell inserted in this step: direction | run, and its expansion number (0xFFFF for one that
+            // was inserted but cut off by the end of the search) - the digest is summed from the hash at the end, off the chain of steps
+            if (inserted && hash_complete) { L.c_info[my_slot] = (uint16_t)(d | (run_in << 4)); L.c_seq[my_slot] = valid ? (uint16_t)seq : (uint16_t)0xFFFFu; }
+            if (valid) {
+                if (!hash_complete) { pin[cell] = (uint16_t)(d | (run_in << 4)); digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell); }
+                if (order && seq < order_cap) order[seq] = cell;
+            }
         }
         if (vm && f > fmax) { fmax = f; n_rounds++; }
         n_exp += __popc(vm);

@@ -113,7 +113,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("DMPP_LIB") or LIB_PATH          # DMPP_LIB: another build of the library (A/B measurements)
     if not os.path.exists(path):
         raise PlannerError(f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')")
     lib = C.CDLL(path)

@@ -192,15 +192,30 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
             //   cosA = (d1 + d2 - d3) / (2 sqrt(d1 d2))   =>   sinA^2 = (4 d1 d2 - (d1 + d2 - d3)^2) / (4 d1 d2),
             //   (1 / R)^2 = sinA^2 / (0.25 d3) = (4 d1 d2 - (d1 + d2 - d3)^2) / (d1 d2 d3).
             // Against the oracle's sqrt / divide chain this differs by rounding only (<= ~1e-9 relative where sinA is at
-            // its fence of 0.001, less elsewhere; the scores are compared to 1e-6).
+            // its fence of 0.001, less elsewhere; the scores are compared to 1e-6) - except AT the fence, see below.
             const GlobalPoint2D pa = cnd[i - 1], pf = cnd[i + 1];
             const double d1 = (pa.x - p.x) * (pa.x - p.x) + (pa.y - p.y) * (pa.y - p.y);
             const double d2 = (p.x - pf.x) * (p.x - pf.x) + (p.y - pf.y) * (p.y - pf.y);
             const double d3 = (pa.x - pf.x) * (pa.x - pf.x) + (pa.y - pf.y) * (pa.y - pf.y);
             const double den2 = 4 * d1 * d2, num = d1 + d2 - d3;
-            const double diff = den2 - num * num;
+            const double diff = den2 - num * num, fence = kk2_fenced * den2;        // sinA >= 0.001  <=>  diff >= fence
             kk2 = kk2_fenced;
-            if (den2 > 0 && diff >= kk2_fenced * den2) kk2 = diff / (d1 * d2 * d3);
+            if (den2 > 0) {
+                if (fabs(diff - fence) <= 1e-6 * fence) {
+                    // The fence is a discontinuity of the specification (1 / R jumps from 0.001 to sinA / (0.5 dis3)), so the side a
+                    // point falls on must be the oracle's own decision, not one taken from a differently rounded expression: where
+                    // the squared form cannot tell (its rounding error is ~1e-9 of the fence for sides of similar length; this band is 1e-6) the
+                    // oracle's chain of operations is evaluated as it stands.  About one point in 1e6 comes here
+                    // (tests/test_oracle_properties.py replays both forms around the fence).
+                    const double dis1 = sqrt(d1), dis2 = sqrt(d2), dis3 = sqrt(d3);
+                    const double den = 2 * dis1 * dis2;
+                    if (den > 0) {
+                        const double cosA = (dis1 * dis1 + dis2 * dis2 - dis3 * dis3) / den;
+                        const double sinA = sqrt(1 - cosA * cosA);
+                        if (sinA >= 0.001) { const double R = 0.5 * dis3 / sinA; const double kq = 1 / R; kk2 = kq * kq; }
+                    }
+                } else if (diff > fence) kk2 = diff / (d1 * d2 * d3);
+            }
         }
     };
     auto publish = [&](int k, double off, double pen_acc, double k2_acc, int first_hit) {      // the whole wave

@@ -212,3 +212,47 @@ def test_dynamic_obstacles_move_with_the_tick(dm, oracle):
     assert np.allclose(o3["x"], sc["obs_pool"]["x"] + sc["mot_pool"]["vx"] * 0.3, rtol=1e-15)
     cfg["dynamic_obstacles"] = 0
     assert oracle.effective_obstacles(cfg, sc["obs_pool"], sc["mot_pool"], 3).tobytes() == sc["obs_pool"].tobytes()
+
+
+def test_curvature_fence_of_the_scoring_kernel_is_decided_by_the_oracle_chain():
+    """k_score sums (1 / R)^2 from SQUARED side lengths (one division, no square root; kernels_score.hpp).  R is fenced to
+    1000 where sinA < 0.001 - a discontinuity of the specification - so a point must fall on the same side of the fence as in
+    the oracle's chain of operations (radius3 in oracle/dmpp_grid_oracle.c), not on the side a differently rounded expression
+    says.  This replays the kernel's arithmetic in numpy (IEEE double, no contraction - as the device build) on triples whose
+    sinA sits within 1e-12 ... 1e-3 (relative) of the fence: the fast form may only ever be used where it agrees with the
+    chain, i.e. every disagreement about the side must lie inside the band the kernel hands to the chain itself."""
+    rng = np.random.default_rng(11)
+    n = 400000
+    L1 = rng.uniform(0.05, 3.0, n); L2 = rng.uniform(0.05, 3.0, n)
+    rel = 10.0 ** rng.uniform(-12, -3, n) * rng.choice([-1.0, 1.0], n)
+    theta = 0.001 * (1.0 + rel)                                   # turning angle ~ sinA
+    phi = rng.uniform(0, 2 * np.pi, n)
+    ax = rng.uniform(-500, 500, n); ay = rng.uniform(-500, 500, n)
+    mx = ax + L1 * np.cos(phi); my = ay + L1 * np.sin(phi)
+    fx = mx + L2 * np.cos(phi + theta); fy = my + L2 * np.sin(phi + theta)
+    # the oracle's chain
+    dis1 = np.sqrt((ax - mx) * (ax - mx) + (ay - my) * (ay - my))
+    dis2 = np.sqrt((mx - fx) * (mx - fx) + (my - fy) * (my - fy))
+    dis3 = np.sqrt((ax - fx) * (ax - fx) + (ay - fy) * (ay - fy))
+    den = 2 * dis1 * dis2
+    cosA = (dis1 * dis1 + dis2 * dis2 - dis3 * dis3) / den
+    with np.errstate(invalid="ignore"):
+        sinA = np.sqrt(1 - cosA * cosA)
+    chain_unfenced = sinA >= 0.001
+    k = 1 / (0.5 * dis3 / np.where(chain_unfenced, sinA, 1.0))
+    chain = np.where(chain_unfenced, k * k, 0.001 * 0.001)
+    # the kernel's squared form
+    d1 = (ax - mx) * (ax - mx) + (ay - my) * (ay - my)
+    d2 = (mx - fx) * (mx - fx) + (my - fy) * (my - fy)
+    d3 = (ax - fx) * (ax - fx) + (ay - fy) * (ay - fy)
+    den2 = 4 * d1 * d2; num = d1 + d2 - d3
+    diff = den2 - num * num; fence = (0.001 * 0.001) * den2
+    band = np.abs(diff - fence) <= 1e-6 * fence
+    fast_unfenced = diff > fence
+    fast = np.where(fast_unfenced, diff / (d1 * d2 * d3), 0.001 * 0.001)
+    sides_differ = fast_unfenced != chain_unfenced
+    assert band.sum() > 100                                      # the sample really probes the band
+    assert not (sides_differ & ~band).any(), int((sides_differ & ~band).sum())
+    kernel = np.where(band, chain, fast)
+    assert np.allclose(kernel, chain, rtol=1e-7, atol=0)         # (outside the band: the squared form, to rounding - ~1e-9 for the
+                                                                 # near-equal sides of a resampled path, more for sides 1 : 60 as drawn here)

@@ -65,7 +65,7 @@ struct pp_planner {
     int bucket_cap0 = 0, max_path0 = 0;
     // search: k_search_lds<kind> with `lds_budget` data words per view in LDS; scenes that need more go to k_search_gbm
     int search_kind = 0; int search_meta_bytes = 0; int lds_budget = 0, lds_budget_max = 0; bool lds_budget_fixed = false, search_force_gbm = false;
-    int gbm_lds = 0; int search_slots = 512;
+    int gbm_lds = 0; int search_slots = 512; size_t search_static_lds = 0;   // static LDS of k_search<kind>
     int32_t* d_ovf[kBuf] = {}; int32_t* d_need[kBuf] = {}; int32_t* h_need = nullptr;   // h_need: pinned, [kBuf], written by k_score (-1: nothing yet)
     int need_seen = 0;
     int* d_gridbad = nullptr;
@@ -174,7 +174,9 @@ int setup_grid_launch(pp_planner* h)
     h->search_kind = lw <= 16 ? 0 : (lw <= 32 ? 1 : 2);
     const size_t per_line = h->search_kind == 0 ? 4 : (h->search_kind == 1 ? 8 : 12);
     h->search_meta_bytes = (int)((((size_t)c.grid_w + c.grid_h) * per_line + 15) & ~(size_t)15);
-    const size_t static_lds = sizeof(dmpp::SearchLds) + 64;
+    h->search_static_lds = h->search_kind == 2 ? sizeof(dmpp::SearchLds<dmpp::closed_log_of<2>()>) : sizeof(dmpp::SearchLds<dmpp::closed_log_of<0>()>);
+    static_assert(dmpp::closed_log_of<0>() == dmpp::closed_log_of<1>(), "one static LDS size for the kinds 0 and 1");
+    const size_t static_lds = h->search_static_lds + 64;
     size_t lds_max = 64u * 1024u;
     {
         int v = 0;
@@ -572,11 +574,11 @@ int pp_plan_tick(pp_handle h)
             }
             h->lds_budget = std::max(64, std::min(want, h->lds_budget_max));
         }
-        const size_t per_wg = sizeof(dmpp::SearchLds) + 64 + std::max((size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget, (size_t)h->gbm_lds);
+        const size_t per_wg = h->search_static_lds + 64 + std::max((size_t)h->search_meta_bytes + 8 * (size_t)h->lds_budget, (size_t)h->gbm_lds);
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / per_wg));       // 4 waves per workgroup while it sets up: <= 8 per CU
         h->search_slots = per_cu * std::max(1, h->n_cus);
     } else if (c.grid_stage) {
-        const size_t per_wg = sizeof(dmpp::SearchLds) + 64 + (size_t)h->gbm_lds;
+        const size_t per_wg = h->search_static_lds + 64 + (size_t)h->gbm_lds;
         h->search_slots = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / per_wg)) * std::max(1, h->n_cus);
     }
     // Consecutive searches overlap: a search ends with a handful of long scenes and would leave most of the chip idle; the searches

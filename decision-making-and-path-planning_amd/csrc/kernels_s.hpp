@@ -48,7 +48,9 @@ __device__ __forceinline__ int hfun(int x, int y, int gx, int gy)
 }
 
 constexpr int kOpenCap = DMPP_OPEN_CAP;
-constexpr int kClosedLog = 9, kClosedTab = 1 << kClosedLog, kClosedMax = 384;      // LDS closed-set hash; beyond kClosedMax the scene spills to HBM
+// LDS closed-set hash: 2^CL slots, at most 3/4 full; beyond that the scene spills to a bit set in HBM (zeroed only then: W * H / 8
+// bytes - 512 KiB at 2048 x 2048, where the line metas already limit a CU to two scenes and a larger hash costs no occupancy)
+template <int K> constexpr int closed_log_of() { return K == 2 ? 10 : 9; }      // LDS closed-set hash; beyond kClosedMax the scene spills to HBM
 constexpr int kDiagK = DMPP_DIAG_JUMP;                  // cells a diagonal jump looks ahead
 constexpr int kDiagGroup = 2 * kDiagK;                  // lanes per diagonal jump: (cell, horizontal | vertical component)
 constexpr int kDiagPerRound = DMPP_WAVE / kDiagGroup;
@@ -481,7 +483,9 @@ __device__ __forceinline__ void sparse_clear_cell(const SparseView<K>& vw, int l
 }
 
 // ---------------------------------------------------------------------------------------
-struct SearchLds {                               // the static LDS of a searching workgroup (12.3 KB)
+template <int CL>
+struct SearchLds {                               // the static LDS of a searching workgroup (8.2 KB at CL = 9)
+    static constexpr int kClosedLog = CL, kClosedTab = 1 << CL, kClosedMax = 3 << (CL - 2);
     uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24
     uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
     uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
@@ -496,10 +500,11 @@ struct SearchLds {                               // the static LDS of a searchin
 struct SearchOut { int status, n_exp, n_push, n_rounds, path_cost, path_len; uint64_t digest; };
 
 // order_digest of the expansions recorded in the closed-set hash: this lane's share of  sum mix64(seq << 32 | cell)
-__device__ __forceinline__ uint64_t hash_digest(const SearchLds& L, int lane)
+template <class LDS>
+__device__ __forceinline__ uint64_t hash_digest(const LDS& L, int lane)
 {
     uint64_t dg = 0;
-    for (int i = lane; i < kClosedTab; i += DMPP_WAVE) {
+    for (int i = lane; i < LDS::kClosedTab; i += DMPP_WAVE) {
         const uint32_t e = L.c_tab[i]; const uint32_t sq = L.c_seq[i];
         if (e && sq != 0xFFFFu) dg += mix64(((uint64_t)sq << 32) | (uint64_t)(e - 1u));
     }
@@ -508,7 +513,8 @@ __device__ __forceinline__ uint64_t hash_digest(const SearchLds& L, int lane)
 
 // Squeezes the dead slots out of the open list, keeping the push order (ballot + prefix popcount); the slots that fall free
 // are marked dead again (the pop relies on 0xFFFF at and beyond n_open).  Returns the new n_open.
-__device__ __forceinline__ int squeeze_open(SearchLds& L, int n_open, int lane)
+template <class LDS>
+__device__ __forceinline__ int squeeze_open(LDS& L, int n_open, int lane)
 {
     int w = 0;
     for (int q0 = 0; q0 < n_open; q0 += DMPP_WAVE) {
@@ -531,8 +537,8 @@ __device__ __forceinline__ int squeeze_open(SearchLds& L, int n_open, int lane)
 }
 
 // The search proper, one wave.  Vrow / Vcol: the two views; closed / pin: this scene's spill area in HBM.
-template <class V>
-__device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchLds& L, const V& Vrow, const V& Vcol, int start, int goal, int order_cap,
+template <class V, class LDS>
+__device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L, const V& Vrow, const V& Vcol, int start, int goal, int order_cap,
                                         uint32_t* __restrict__ closed, uint16_t* __restrict__ pin, int32_t* __restrict__ order,
                                         int32_t* __restrict__ path, int lane
 #ifdef DMPP_DEBUG_SEARCH
@@ -546,6 +552,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, SearchL
 #else
 #define DBG_MARK(slot)
 #endif
+    constexpr int kClosedLog = LDS::kClosedLog, kClosedTab = LDS::kClosedTab, kClosedMax = LDS::kClosedMax;
     const int W = c.grid_w, H = c.grid_h, N = W * H;
     const int gx = goal % W, gy = goal / W;
     const int cap = min(c.bucket_cap, kOpenCap);
@@ -1008,7 +1015,8 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t
 {
     // static LDS: SearchLds; dynamic LDS: [line metas of both views | `budget` data words per view]
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ SearchLds L;
+    using LdsT = SearchLds<closed_log_of<K>()>;
+    __shared__ LdsT L;
     constexpr unsigned kViewsAt = 0;
     if ((int)blockIdx.x >= n_scenes) return;
     const long long t_begin = clock64();
@@ -1034,7 +1042,7 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t
         vr.data = (DMPP_LDS uint32_t*)(p + used); vc.data = vr.data + budget;
         vr.LW = WW; vr.NL = H; vc.LW = HW; vc.NL = W;
     }
-    for (int i = tid; i < kClosedTab; i += (SW * DMPP_WAVE)) L.c_tab[i] = 0;
+    for (int i = tid; i < LdsT::kClosedTab; i += (SW * DMPP_WAVE)) L.c_tab[i] = 0;
     for (int i = tid; i < kOpenCap; i += (SW * DMPP_WAVE)) L.o_f2[i] = 0xFFFFu;      // dead slots everywhere: the pop never range-checks
     const ObPoint* obs = obs_now + si.obs_off;
 #ifdef DMPP_DEBUG_SEARCH

@@ -261,7 +261,9 @@ __device__ __forceinline__ bool exact_span(double ou, double org, double cell, d
 {
     if (dv2 > R2) return false;                            // du*du >= 0: no index can satisfy the predicate
     auto pred = [&](int i) { const double du = (org + ((double)i + 0.5) * cell) - ou; return du * du + dv2 <= R2; };
-    const double half = sqrt(R2 - dv2);                    // (double: a single-precision estimate misses the certificate too often)
+    // only an estimate (the predicate certifies the ends): the raw hardware square root (~2^-26 relative), without the refinement
+    // to a correctly rounded one (a single-precision estimate misses the certificate too often)
+    const double half = __builtin_amdgcn_sqrt(R2 - dv2);
     a = clampi((int)ceil((ou - half - org) * inv_cell - 0.5), lo - 1, hi + 1);
     b = clampi((int)floor((ou + half - org) * inv_cell - 0.5), lo - 1, hi + 1);
     const bool pa = pred(a), pa1 = pred(a - 1), pb = pred(b), pb1 = pred(b + 1);          // four independent evaluations, no short-circuit

@@ -585,8 +585,8 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
         // The kernel ends with its longest search, and several searching waves share a SIMD: a search that has already run
         // long issues ahead of the fresh ones (and of the set-up waves, which run at the lowest priority)
-        if (steps == 24) __builtin_amdgcn_s_setprio(2);
-        if (steps == 56) __builtin_amdgcn_s_setprio(3);
+        if (steps == 12) __builtin_amdgcn_s_setprio(2);
+        if (steps == 36) __builtin_amdgcn_s_setprio(3);
         steps++;
 #ifdef DMPP_DEBUG_SEARCH
         dbg_c[0]++;

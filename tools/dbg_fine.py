@@ -1,4 +1,6 @@
-# temporary: finer phase split of the search step (debug build with the extra marks)
+# Finer phase split of the search step than tools/dbg_timing.py: needs the debug build (make -C .../csrc debug), whose extra
+# marks (DBG_MARK 7..11 in kernels_s.hpp) stamp job hand-over, line descriptors, cell tests, scans and successor rules.
+#   gpurun -- 'python tools/dbg_fine.py'
 import sys
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import os

@@ -211,7 +211,8 @@ __device__ __forceinline__ int jump_lane(const V& vw, const L& m0, const L& mP, 
     for (int it = 0; it <= vw.LW; it++) {
         if (!wave_ballot(go)) break;
         if (iters) ++*iters;
-        const int wi = !go ? w0 : (fwd ? lsb_m(cand) : msb_m(cand));
+        const int wlo = lsb_m(cand), whi = msb_m(cand);
+        const int wi = !go ? w0 : (fwd ? wlo : whi);
         cand &= (M)~(((M)1) << wi);
         const int wn = wi + sgn;
         uint32_t B0 = vw.word(m0, wi), P = vw.word(mP, wi), Mi = vw.word(mM, wi), Pw = vw.word(mP, wn), Mw = vw.word(mM, wn);
@@ -220,12 +221,13 @@ __device__ __forceinline__ int jump_lane(const V& vw, const L& m0, const L& mP, 
         uint32_t stop = B0 | (P & ~Pn) | (Mi & ~Mn);
         if (goal_line && (gpos >> 5) == wi) stop |= 1u << gb;
         if (wi == w0) stop &= ahead;
-        if (go) {
-            if (stop) {
-                const int bit = __ffs((int)stop) - 1;
-                if (!((B0 >> bit) & 1u)) { const int np = (wi << 5) + (fwd ? bit : 31 - bit); run = fwd ? np - pos : pos - np; }
-                go = false;
-            } else if (cand == 0) go = false;                // free all the way to the edge of the grid: no jump point
+        {   // selects, no branches: the first stop of the word ends the scan (a blocked one with run 0); no stop and no
+            // candidate word left: free all the way to the edge of the grid, no jump point
+            const int bit = (__ffs((int)stop) - 1) & 31;
+            const int np = (wi << 5) + (fwd ? bit : 31 - bit);
+            const int rr = fwd ? np - pos : pos - np;
+            run = (go && stop != 0u && !((B0 >> bit) & 1u)) ? rr : run;
+            go = go && stop == 0u && cand != 0;
         }
     }
     return run;
@@ -485,6 +487,52 @@ __device__ __forceinline__ void sparse_clear_cell(const SparseView<K>& vw, int l
 }
 
 // ---------------------------------------------------------------------------------------
+// The successor rules of jump-point search as lookup tables: what direction s is for a node reached in
+// direction d (8 = the start node) - 1: a straight jump, 2: a diagonal jump in the natural direction, 3: a diagonal jump
+// that needs a blocked side cell, 0: nothing - and where that side cell lies.  The tables are generated at compile time from
+// the rules as the oracle states them (rule_code / side_offset below), so they cannot drift from them.
+namespace rules {
+constexpr int dxs(int s) { return (s == 0 || s == 1 || s == 7) ? 1 : ((s >= 3 && s <= 5) ? -1 : 0); }
+constexpr int dys(int s) { return (s >= 1 && s <= 3) ? 1 : ((s >= 5) ? -1 : 0); }
+constexpr int rule_code(int d, int s)
+{
+    const int rel = (s - d) & 7;
+    const bool is_start = d == 8, d_odd = (d & 1) != 0 && !is_start, d_even = !d_odd && !is_start;
+    const bool jump0 = (is_start && (s & 1) == 0) || (d_even && rel == 0) || (d_odd && (rel == 1 || rel == 7));
+    const bool plain = (is_start && (s & 1) != 0) || (d_odd && rel == 0);
+    const bool sided = (d_even && (rel == 1 || rel == 7)) || (d_odd && (rel == 2 || rel == 6));
+    return jump0 ? 1 : (plain ? 2 : (sided ? 3 : 0));
+}
+constexpr int side_offset(int d, int s, bool want_y)       // the side cell of a "3" successor, relative to the node
+{
+    const bool d_odd = (d & 1) != 0 && d != 8;
+    const int a = want_y ? dys(s) - dys(d & 7) : dxs(s) - dxs(d & 7);
+    return d_odd ? a / 2 : a;
+}
+constexpr uint64_t code_rows(int d0)                        // rows d0 .. d0 + 3: 16 bits per row, 2 bits per direction
+{
+    uint64_t t = 0;
+    for (int d = d0; d < d0 + 4; d++) for (int s = 0; s < 8; s++) t |= (uint64_t)rule_code(d, s) << ((d - d0) * 16 + 2 * s);
+    return t;
+}
+constexpr uint32_t start_row() { uint32_t t = 0; for (int s = 0; s < 8; s++) t |= (uint32_t)rule_code(8, s) << (2 * s); return t; }
+constexpr uint32_t kDxTab = 0x901Au, kDyTab = 0x01A9u;     // dx + 1 / dy + 1 of a direction, 2 bits each
+constexpr bool tables_ok()
+{
+    for (int d = 0; d < 8; d++) if (((int)((kDxTab >> (2 * d)) & 3u) - 1) != dxs(d) || ((int)((kDyTab >> (2 * d)) & 3u) - 1) != dys(d)) return false;
+    // the device code takes the side offset as (ds - dd) >> (d & 1): equal to side_offset wherever the code is 3
+    for (int d = 0; d <= 8; d++) for (int s = 0; s < 8; s++) if (rule_code(d, s) == 3) {
+        const int ax = dxs(s) - dxs(d & 7), ay = dys(s) - dys(d & 7);
+        if ((ax >> (d & 1)) != side_offset(d, s, false) || (ay >> (d & 1)) != side_offset(d, s, true)) return false;
+    }
+    return true;
+}
+static_assert(tables_ok(), "direction tables / side offsets");
+constexpr uint64_t kCodeLo = code_rows(0), kCodeHi = code_rows(4);
+constexpr uint32_t kCodeStart = start_row();
+}  // namespace rules
+
+// ---------------------------------------------------------------------------------------
 template <int CL>
 struct SearchLds {                               // the static LDS of a searching workgroup (8.2 KB at CL = 9)
     static constexpr int kClosedLog = CL, kClosedTab = 1 << CL, kClosedMax = 3 << (CL - 2);
@@ -638,18 +686,16 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         const int gcur = f - hfun(x, y, gx, gy);
         bool jump0, diag0;
         {
+            // the rule for (arriving direction d, direction s) and the side cell of a forced diagonal: table lookups (namespace rules)
             const int dd = d & 7;
-            const int ddx = (dd == 0 || dd == 1 || dd == 7) ? 1 : ((dd >= 3 && dd <= 5) ? -1 : 0);
-            const int ddy = (dd >= 1 && dd <= 3) ? 1 : ((dd >= 5) ? -1 : 0);
-            const int rel = (s - d) & 7;
-            const bool is_start = d == 8, d_odd = (d & 1) != 0 && !is_start, d_even = !d_odd && !is_start;
-            jump0 = (is_start && (s & 1) == 0) || (d_even && rel == 0) || (d_odd && (rel == 1 || rel == 7));
-            const bool plain = (is_start && (s & 1) != 0) || (d_odd && rel == 0);
-            const bool sided = (d_even && (rel == 1 || rel == 7)) || (d_odd && (rel == 2 || rel == 6));
-            const int px = d_odd ? (sdx - ddx) / 2 : sdx - ddx, py = d_odd ? (sdy - ddy) / 2 : sdy - ddy;
+            const uint32_t row = d >= 8 ? rules::kCodeStart : (uint32_t)((d < 4 ? rules::kCodeLo : rules::kCodeHi) >> ((d & 3) * 16));
+            const uint32_t code = (row >> (2 * s)) & 3u;
+            jump0 = code == 1u;
+            const int ddx = (int)((rules::kDxTab >> (2 * dd)) & 3u) - 1, ddy = (int)((rules::kDyTab >> (2 * dd)) & 3u) - 1;
+            const int px = (sdx - ddx) >> (d & 1), py = (sdy - ddy) >> (d & 1);
             const bool t_blk = cell_blocked(Vrow, x + sdx, y + sdy);
             const bool side_blk = cell_blocked(Vrow, x + px, y + py);
-            diag0 = !t_blk && (plain || (sided && side_blk));
+            diag0 = !t_blk && (code == 2u || (code == 3u && side_blk));
         }
         DBG_MARK(11)
         // ---- closed?  duplicates inside the batch: the earlier one wins; then the closed set (lanes with s == 0) ----

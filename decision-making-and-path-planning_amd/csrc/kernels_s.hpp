@@ -630,7 +630,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
     long long guard = 16ll * N + 1024;                 // every iteration pops an entry; entries <= 8 per closed cell
     int steps = 0;
     while (status < 0) {
-        if (--guard < 0) { status = DMPP_G_INTERNAL; break; }
+        if (__builtin_expect(--guard < 0, 0)) { status = DMPP_G_INTERNAL; break; }
         // The kernel ends with its longest search, and several searching waves share a SIMD: a search that has already run
         // long issues ahead of the fresh ones (and of the set-up waves, which run at the lowest priority)
         if (steps == 12) __builtin_amdgcn_s_setprio(2);
@@ -642,14 +642,14 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         if (live == 0) { status = DMPP_G_NO_PATH; break; }
         // ---- pop: up to 4 entries of the smallest f, the latest pushes first ----
         // (1) squeeze the dead slots out when they outnumber the live ones: the scans below stay short
-        if ((n_open - live > 64 && n_open > 2 * live)) n_open = squeeze_open(L, n_open, lane);
+        if (__builtin_expect(n_open - live > 64 && n_open > 2 * live, 0)) n_open = squeeze_open(L, n_open, lane);
         // (2) the keys, 64 slots per register; slots at and beyond n_open always hold 0xFFFF, so nothing is range-checked
         const uint32_t v0 = L.o_f2[lane], v1 = L.o_f2[lane + 64], v2 = L.o_f2[lane + 128], v3 = L.o_f2[lane + 192];
         uint32_t v4 = 0xFFFFu, v5 = 0xFFFFu, v6 = 0xFFFFu, v7 = 0xFFFFu;
         const bool upper = n_open > 256;
-        if (upper) { v4 = L.o_f2[lane + 256]; v5 = L.o_f2[lane + 320]; v6 = L.o_f2[lane + 384]; v7 = L.o_f2[lane + 448]; }
+        if (__builtin_expect(upper, 0)) { v4 = L.o_f2[lane + 256]; v5 = L.o_f2[lane + 320]; v6 = L.o_f2[lane + 384]; v7 = L.o_f2[lane + 448]; }
         const uint32_t fmin2 = wave_min_u32(min(min(min(v0, v1), min(v2, v3)), min(min(v4, v5), min(v6, v7))));
-        if (fmin2 == 0xFFFFu) { status = DMPP_G_INTERNAL; break; }
+        if (__builtin_expect(fmin2 == 0xFFFFu, 0)) { status = DMPP_G_INTERNAL; break; }
         const int f = (int)fmin2 << 1;
         // the (<= 4) slots taken, 16 bits each, first taken in the low bits (scalar: the tie masks are wave-uniform)
         int nt = 0; unsigned long long sel = 0;
@@ -663,7 +663,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
                 nt++;                                                                                \
             }                                                                                        \
         }
-        if (upper) { DMPP_TAKE(v7, 448) DMPP_TAKE(v6, 384) DMPP_TAKE(v5, 320) DMPP_TAKE(v4, 256) }
+        if (__builtin_expect(upper, 0)) { DMPP_TAKE(v7, 448) DMPP_TAKE(v6, 384) DMPP_TAKE(v5, 320) DMPP_TAKE(v4, 256) }
         DMPP_TAKE(v3, 192) DMPP_TAKE(v2, 128) DMPP_TAKE(v1, 64) DMPP_TAKE(v0, 0)
 #undef DMPP_TAKE
         static_assert(DMPP_JPS_BATCH == 4 && kOpenCap <= 65536, "four 16-bit slot numbers in one 64-bit scalar");
@@ -706,7 +706,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
                 (node == 3 && (cell == c0_ || cell == c1_ || cell == c2_))) valid = false;
         }
         uint32_t my_slot = 0;
-        if (n_exp + DMPP_JPS_BATCH <= kClosedMax) {
+        if (__builtin_expect(n_exp + DMPP_JPS_BATCH <= kClosedMax, 1)) {
             // first probe in straight-line code (nearly always the last); a collision chain is walked in a wave-uniform loop
             const uint32_t keyc = (uint32_t)cell + 1u;
             uint32_t hh = ((uint32_t)cell * 2654435761u) >> (32 - kClosedLog);
@@ -754,7 +754,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         {   // the goal, or the entry that reaches the expansion limit, ends the search at once
             const int nvb = __popc(vm & ((1u << node) - 1u));
             const unsigned stop = nodes_of(wave_ballot(valid && (cell == goal || n_exp + nvb + 1 >= c.max_expansions)));
-            if (stop) {
+            if (__builtin_expect(stop != 0, 0)) {
                 const int last = __ffs((int)stop) - 1;
                 if (node > last) valid = false;
                 vm = nodes_of(wave_ballot(valid));
@@ -863,13 +863,13 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
             // f/2 lives in 16 bits (0xFFFF = dead slot): a push at or beyond DMPP_F_LIMIT ends the search.  The oracle tests
             // each push in turn, the range before the capacity: the earlier of the two failing pushes decides the status.
             const unsigned rm = (unsigned)wave_ballot(push && fn >= DMPP_F_LIMIT);
-            if (rm || live + cnt > cap) {
+            if (__builtin_expect(rm || live + cnt > cap, 0)) {
                 const int k_range = rm ? __popc(pm & ((1u << (__ffs((int)rm) - 1)) - 1u)) : 0x7FFFFFFF;
                 const int k_cap = live + cnt > cap ? cap - live : 0x7FFFFFFF;
                 status = k_range <= k_cap ? DMPP_G_COST_RANGE : DMPP_G_OVERFLOW;
                 break;
             }
-            if (n_open + cnt > kOpenCap) n_open = squeeze_open(L, n_open, lane);      // keeps the push order
+            if (__builtin_expect(n_open + cnt > kOpenCap, 0)) n_open = squeeze_open(L, n_open, lane);      // keeps the push order
             if (push) {
                 const int slot = n_open + __popc(pm & ((1u << lane) - 1u));
                 L.o_f2[slot] = (uint16_t)(fn >> 1);

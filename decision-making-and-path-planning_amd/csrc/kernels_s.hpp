@@ -639,7 +639,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
 #ifdef DMPP_DEBUG_SEARCH
         dbg_c[0]++;
 #endif
-        if (live == 0) { status = DMPP_G_NO_PATH; break; }
+        if (__builtin_expect(live == 0, 0)) { status = DMPP_G_NO_PATH; break; }
         // ---- pop: up to 4 entries of the smallest f, the latest pushes first ----
         // (1) squeeze the dead slots out when they outnumber the live ones: the scans below stay short
         if (__builtin_expect(n_open - live > 64 && n_open > 2 * live, 0)) n_open = squeeze_open(L, n_open, lane);
@@ -772,9 +772,9 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         }
         if (vm && f > fmax) { fmax = f; n_rounds++; }
         n_exp += __popc(vm);
-        if (wave_ballot(valid && cell == goal)) { status = DMPP_G_FOUND; path_cost = f; break; }
-        if (n_exp >= c.max_expansions) { status = DMPP_G_LIMIT; break; }
-        if (vm == 0) continue;
+        if (__builtin_expect(wave_ballot(valid && cell == goal) != 0, 0)) { status = DMPP_G_FOUND; path_cost = f; break; }
+        if (__builtin_expect(n_exp >= c.max_expansions, 0)) { status = DMPP_G_LIMIT; break; }
+        if (__builtin_expect(vm == 0, 0)) continue;
         DBG_MARK(1)
         const bool nvalid = lane < 32 && ((vm >> node) & 1u);
         const bool want_jump = nvalid && jump0, want_diag = nvalid && diag0;
@@ -857,7 +857,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         const bool push = run > 0;
         const unsigned pm = (unsigned)wave_ballot(push);
         const int cnt = __popc(pm);
-        if (cnt) {
+        if (__builtin_expect(cnt != 0, 1)) {
             const int nx = x + run * sdx, ny = y + run * sdy;
             const int fn = gcur + run * ((s & 1) ? 14 : 10) + hfun(nx, ny, gx, gy);
             // f/2 lives in 16 bits (0xFFFF = dead slot): a push at or beyond DMPP_F_LIMIT ends the search.  The oracle tests

@@ -675,7 +675,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         wave_order();
         if (have && s == 0) L.o_f2[myi] = 0xFFFFu;
         live -= nt;
-        if (i0 == n_open - 1) n_open--;
+        n_open -= (i0 == n_open - 1) ? 1 : 0;
         const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu), d = (int)(e >> 24);
         const int cell = y * W + x;
         DBG_MARK(0)
@@ -764,9 +764,9 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
             const int seq = n_exp + __popc(vm & ((1u << node) - 1u));
             // the hash entry of every cell inserted in this step: direction | run, and its expansion number (0xFFFF for one that
             // was inserted but cut off by the end of the search) - the digest is summed from the hash at the end, off the chain of steps
-            if (inserted && hash_complete) { L.c_info[my_slot] = (uint16_t)(d | (run_in << 4)); L.c_seq[my_slot] = valid ? (uint16_t)seq : (uint16_t)0xFFFFu; }
+            if (inserted && __builtin_expect(hash_complete, 1)) { L.c_info[my_slot] = (uint16_t)(d | (run_in << 4)); L.c_seq[my_slot] = valid ? (uint16_t)seq : (uint16_t)0xFFFFu; }
             if (valid) {
-                if (!hash_complete) { pin[cell] = (uint16_t)(d | (run_in << 4)); digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell); }
+                if (__builtin_expect(!hash_complete, 0)) { pin[cell] = (uint16_t)(d | (run_in << 4)); digest += mix64(((uint64_t)(uint32_t)seq << 32) | (uint32_t)cell); }
                 if (order && seq < order_cap) order[seq] = cell;
             }
         }

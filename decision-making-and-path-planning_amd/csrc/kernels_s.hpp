@@ -269,7 +269,7 @@ __device__ __forceinline__ bool exact_span(double ou, double org, double cell, d
     a = clampi((int)ceil((ou - half - org) * inv_cell - 0.5), lo - 1, hi + 1);
     b = clampi((int)floor((ou + half - org) * inv_cell - 0.5), lo - 1, hi + 1);
     const bool pa = pred(a), pa1 = pred(a - 1), pb = pred(b), pb1 = pred(b + 1);          // four independent evaluations, no short-circuit
-    if (!((a <= b) & pa & !pa1 & pb & !pb1)) {
+    if (__builtin_expect(!((a <= b) & pa & !pa1 & pb & !pb1), 0)) {
         // an empty run (the common reason: the footprint only grazes the line), or - rarely - an estimate one off.  A run that
         // is not empty contains the index nearest to ou: three evaluations certify emptiness; otherwise both ends are walked.
         const bool c0 = pred(ic), c1 = pred(ic - 1), c2 = pred(ic + 1);

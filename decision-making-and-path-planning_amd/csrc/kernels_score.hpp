@@ -162,7 +162,7 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
     // penalty and squared curvature of point i (= p) of the candidate whose points lie in cnd[]
     auto point_terms = [&](const GlobalPoint2D* cnd, int i, const GlobalPoint2D p, double& pen, double& kk2, bool& hit) {
         double clear = __builtin_inf();
-        if (culled) {
+        if (__builtin_expect(culled, 1)) {
             for (int j = 0; j < n_rel; j++) {
                 const double dx = p.x - sh.rx[j], dy = p.y - sh.ry[j];
                 const double d2 = dx * dx + dy * dy;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
             const double diff = den2 - num * num, fence = kk2_fenced * den2;        // sinA >= 0.001  <=>  diff >= fence
             kk2 = kk2_fenced;
             if (den2 > 0) {
-                if (fabs(diff - fence) <= 1e-6 * fence) {
+                if (__builtin_expect(fabs(diff - fence) <= 1e-6 * fence, 0)) {
                     // The fence is a discontinuity of the specification (1 / R jumps from 0.001 to sinA / (0.5 dis3)), so the side a
                     // point falls on must be the oracle's own decision, not one taken from a differently rounded expression: where
                     // the squared form cannot tell (its rounding error is ~1e-9 of the fence for sides of similar length; this band is 1e-6) the

@@ -9,6 +9,10 @@ namespace dmpp {
 // NW waves per scene score the candidates NW at a time: 4 for batches (four scenes per CU), 16 for the few scenes of a
 // latency-bound tick (17 candidates in 2 rounds instead of 5).
 constexpr int kBoxWaves = 4;
+constexpr int kTailRounds = 4, kTailFirst = 190;      // packed fourth pass: candidates per wave, first point kept for it
+template <int NW> constexpr bool kPackTail = NW <= 4;
+template <int NW> constexpr int kTailWaves = NW <= 4 ? NW : 1;
+static_assert(DMPP_PATH_POINTS - 192 == 8 && kTailFirst == 190 && kTailRounds * 8 <= DMPP_WAVE, "packed fourth pass: lane 8 c + j = point 192 + j of candidate c");
 static_assert(DMPP_PATH_POINTS <= kBoxWaves * DMPP_WAVE && DMPP_MAX_LATTICE <= 32, "score_body: lane layouts");
 constexpr int kMaxRelObs = 128;      // culled obstacle list kept in LDS; a scene with more candidates near its paths reads the whole list from HBM
 template <int NW>
@@ -23,6 +27,7 @@ struct ScoreShared {
     GlobalPoint2D T;                         // terminal point
     double cost[DMPP_MAX_LATTICE];
     int box[4][4];                           // per wave: min / max cell column and row of the grid-path prefix
+    GlobalPoint2D tail[kTailWaves<NW>][kTailRounds][DMPP_PATH_POINTS - kTailFirst];   // points 190 .. 199 of a wave's candidates (packed fourth pass)
     int best, n_rel;
 };
 
@@ -230,9 +235,13 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
     // points, one quarter per wave, when the waves suffice (4 * left <= NW); the per-lane partial sums are then added in the
     // order of the quarters, which is the order one wave would have added them in.
     const int left = nc % NW, n_whole = (4 * left <= NW) ? nc - left : nc;
-    for (int k = wave; k < n_whole; k += NW) {
-        double off = 0;
+    // One whole candidate: passes 0 .. n_pass - 1 over its points (64 per pass).  The fourth pass holds only the points 192 .. 199:
+    // a wave that scores several candidates (four waves per scene) leaves it out and runs ONE packed pass for all of them at the
+    // end - lane 8 c + j takes point 192 + j of its c-th candidate - and then adds each term to the lane that would have added it
+    // (lane j, after its three earlier terms: the order of the sums does not change).
+    auto whole_candidate = [&](int k, int n_pass, double& off, double& pen_acc, double& k2_acc, int& first_hit, GlobalPoint2D* tail) {
         GlobalPoint2D P[4];
+        off = 0;
         if (k < nl) {
             const Bezier bz = sh.bz[k];
             off = (double)(k - (nl - 1) / 2) * c.lattice_step;
@@ -247,20 +256,56 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) if (lane + 64 * q < DMPP_PATH_POINTS) cand[lane + 64 * q] = P[q];
+        if (tail) {                                        // points 190 .. 199 for the packed pass
+            if (lane >= kTailFirst - 128 && lane < 64) tail[lane - (kTailFirst - 128)] = P[2];            // 190, 191 (lanes 62, 63 of pass 2)
+            if (lane < DMPP_PATH_POINTS - 192) tail[192 - kTailFirst + lane] = P[3];                      // 192 .. 199
+        }
         wave_sync();
-        double pen_acc = 0, k2_acc = 0; int first_hit = DMPP_PATH_POINTS;
+        pen_acc = 0; k2_acc = 0; first_hit = DMPP_PATH_POINTS;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int i = lane + 64 * q;
-            if (i < DMPP_PATH_POINTS) {
+            if (q < n_pass && i < DMPP_PATH_POINTS) {
                 double pen, kk2; bool hit;
                 point_terms(cand, i, P[q], pen, kk2, hit);
                 pen_acc += pen; k2_acc += kk2;
                 if (hit && i < first_hit) first_hit = i;
             }
         }
-        publish(k, off, pen_acc, k2_acc, first_hit);
         wave_sync();
+    };
+    const int rounds = (n_whole - wave + NW - 1) / NW;                 // whole candidates of this wave
+    const bool pack_tail = kPackTail<NW> && (n_whole + NW - 1) / NW >= 2 && (n_whole + NW - 1) / NW <= kTailRounds;       // (uniform over the block)
+    if (!pack_tail) {
+        for (int k = wave; k < n_whole; k += NW) {
+            double off, pen_acc, k2_acc; int first_hit;
+            whole_candidate(k, 4, off, pen_acc, k2_acc, first_hit, nullptr);
+            publish(k, off, pen_acc, k2_acc, first_hit);
+        }
+    } else {
+        double accP[kTailRounds], accK[kTailRounds], accOff[kTailRounds]; int accH[kTailRounds];
+#pragma unroll
+        for (int ci = 0; ci < kTailRounds; ci++) {
+            accP[ci] = 0; accK[ci] = 0; accOff[ci] = 0; accH[ci] = DMPP_PATH_POINTS;
+            if (ci < rounds) whole_candidate(wave + ci * NW, 3, accOff[ci], accP[ci], accK[ci], accH[ci], &sh.tail[wave % kTailWaves<NW>][ci][0]);
+        }
+        {   // the packed pass: lane 8 c + j = point 192 + j of candidate c
+            const int cl = lane >> 3, i = 192 + (lane & 7);
+            double pen = 0, kk2 = 0; bool hit = false;
+            if (cl < rounds) {
+                const GlobalPoint2D* cnd = &sh.tail[wave % kTailWaves<NW>][cl][0] - kTailFirst;      // cnd[i] = point i, i = 190 .. 199
+                point_terms(cnd, i, cnd[i], pen, kk2, hit);
+            }
+            const int hv = hit ? i : DMPP_PATH_POINTS;
+#pragma unroll
+            for (int ci = 0; ci < kTailRounds; ci++) {
+                const double vp = shfl_f64(pen, 8 * ci + (lane & 7)), vk = shfl_f64(kk2, 8 * ci + (lane & 7));
+                const int vh = __shfl(hv, 8 * ci + (lane & 7), 64);
+                if (ci < rounds && lane < DMPP_PATH_POINTS - 192) { accP[ci] += vp; accK[ci] += vk; accH[ci] = min(accH[ci], vh); }
+            }
+        }
+#pragma unroll
+        for (int ci = 0; ci < kTailRounds; ci++) if (ci < rounds) publish(wave + ci * NW, accOff[ci], accP[ci], accK[ci], accH[ci]);
     }
     if (n_whole < nc) {
         struct Part { double pen[DMPP_WAVE], k2[DMPP_WAVE]; int hit[DMPP_WAVE]; };

@@ -212,7 +212,7 @@ __device__ __forceinline__ int jump_lane(const V& vw, const L& m0, const L& mP, 
         if (!wave_ballot(go)) break;
         if (iters) ++*iters;
         const int wlo = lsb_m(cand), whi = msb_m(cand);
-        const int wi = !go ? w0 : (fwd ? wlo : whi);
+        const int wi = !go ? 0 : (fwd ? wlo : whi);            // (a lane that is done reads word 0 of its lines: harmless)
         cand &= (M)~(((M)1) << wi);
         const int wn = wi + sgn;
         uint32_t B0 = vw.word(m0, wi), P = vw.word(mP, wi), Mi = vw.word(mM, wi), Pw = vw.word(mP, wn), Mw = vw.word(mM, wn);

@@ -48,6 +48,7 @@ __device__ __forceinline__ int hfun(int x, int y, int gx, int gy)
 }
 
 constexpr int kOpenCap = DMPP_OPEN_CAP;
+constexpr uint32_t kEntryForcedA = 1u, kEntryForcedB = 2u, kEntryAheadBlocked = 4u;      // bits 28.. of an open-list entry
 // LDS closed-set hash: 2^CL slots, at most 3/4 full; beyond that the scene spills to a bit set in HBM (zeroed only then: W * H / 8
 // bytes - 512 KiB at 2048 x 2048, where the line metas already limit a CU to two scenes and a larger hash costs no occupancy)
 template <int K> constexpr int closed_log_of() { return K == 2 ? 10 : 9; }      // LDS closed-set hash; beyond kClosedMax the scene spills to HBM
@@ -179,8 +180,8 @@ __device__ __forceinline__ bool cell_blocked_m(const V& v, const L& m, int p)   
     return (v.word(m, p >> 5) >> (p & 31)) & 1u;             // word(): all ones beyond either end of the line
 }
 
-// run = cells travelled from `pos` along `line` in direction sgn to the first stop (blocked | forced | goal);
-// 0 = none (the first stop is a wall or the edge of the grid).  Safe for starts outside the grid (returns 0).
+// run (bits 0..11 of the result) = cells travelled from `pos` along `line` in direction sgn to the first stop (blocked | forced |
+// goal); 0 = none (the first stop is a wall or the edge of the grid); bits 12 / 13: see the end of the loop.  Safe for starts outside the grid (returns 0).
 // Only words whose mask bit is set in the line or one of its two neighbours (or that hold the goal) can contain a stop:
 // those candidate words are visited in travel order, nothing else is read.  m0 / mP / mM: the line and its neighbours
 // line + 1 / line - 1, loaded by the caller (the diagonal jump's cell tests share them).
@@ -226,7 +227,10 @@ __device__ __forceinline__ int jump_lane(const V& vw, const L& m0, const L& mP, 
             const int bit = (__ffs((int)stop) - 1) & 31;
             const int np = (wi << 5) + (fwd ? bit : 31 - bit);
             const int rr = fwd ? np - pos : pos - np;
-            run = (go && stop != 0u && !((B0 >> bit) & 1u)) ? rr : run;
+            // with the run: was the stop forced from the line + 1 / line - 1 side (bits 12 / 13)?  The node the run ends at
+            // needs exactly these two bits for its own successor rules (search_core), so they travel with it.
+            const uint32_t fP = ((P & ~Pn) >> bit) & 1u, fM = ((Mi & ~Mn) >> bit) & 1u;
+            run = (go && stop != 0u && !((B0 >> bit) & 1u)) ? (int)((uint32_t)rr | (fP << 12) | (fM << 13)) : run;
             go = go && stop == 0u && cand != 0;
         }
     }
@@ -536,7 +540,7 @@ constexpr uint32_t kCodeStart = start_row();
 template <int CL>
 struct SearchLds {                               // the static LDS of a searching workgroup (8.2 KB at CL = 9)
     static constexpr int kClosedLog = CL, kClosedTab = 1 << CL, kClosedMax = 3 << (CL - 2);
-    uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24
+    uint32_t o_ent[kOpenCap];       // x | y << 12 | arriving direction << 24 | kEntry* flags << 28
     uint16_t o_f2[kOpenCap];        // f / 2, 0xFFFF = dead slot
     uint16_t o_run[kOpenCap];       // run length of the move that reached the cell
     uint32_t c_tab[kClosedTab];     // closed cells (cell + 1, 0 = empty): open addressing, linear probing
@@ -676,7 +680,8 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         if (have && s == 0) L.o_f2[myi] = 0xFFFFu;
         live -= nt;
         n_open -= (i0 == n_open - 1) ? 1 : 0;
-        const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu), d = (int)(e >> 24);
+        const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu), d = (int)((e >> 24) & 15u);
+        const uint32_t eflags = e >> 28;         // what the jump that created the entry saw beside / ahead of it (kEntry*)
         const int cell = y * W + x;
         DBG_MARK(0)
 #ifdef DMPP_DEBUG_SEARCH
@@ -686,16 +691,18 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         const int gcur = f - hfun(x, y, gx, gy);
         bool jump0, diag0;
         {
-            // the rule for (arriving direction d, direction s) and the side cell of a forced diagonal: table lookups (namespace rules)
-            const int dd = d & 7;
+            // the rule for (arriving direction d, direction s): a table lookup (namespace rules).  A forced diagonal needs a blocked
+            // side cell and a free target; the plain diagonal a free target: the jump that created the entry has seen those cells
+            // and left the answers in the entry (kEntryForcedA / B: the diagonal on the counter-clockwise / clockwise side of d,
+            // kEntryAheadBlocked: the next cell of the diagonal) - no cell is read here.  The start node has no such record: its
+            // diagonals are simply tried (a blocked target ends the jump with run 0).
             const uint32_t row = d >= 8 ? rules::kCodeStart : (uint32_t)((d < 4 ? rules::kCodeLo : rules::kCodeHi) >> ((d & 3) * 16));
             const uint32_t code = (row >> (2 * s)) & 3u;
             jump0 = code == 1u;
-            const int ddx = (int)((rules::kDxTab >> (2 * dd)) & 3u) - 1, ddy = (int)((rules::kDyTab >> (2 * dd)) & 3u) - 1;
-            const int px = (sdx - ddx) >> (d & 1), py = (sdy - ddy) >> (d & 1);
-            const bool t_blk = cell_blocked(Vrow, x + sdx, y + sdy);
-            const bool side_blk = cell_blocked(Vrow, x + px, y + py);
-            diag0 = !t_blk && (code == 2u || (code == 3u && side_blk));
+            const int rel = (s - d) & 7;
+            const bool forced = ((rel <= 2 ? eflags >> 0 : eflags >> 1) & 1u) != 0;
+            const bool ahead_free = (eflags & kEntryAheadBlocked) == 0;
+            diag0 = (code == 2u && ahead_free) || (code == 3u && forced);
         }
         DBG_MARK(11)
         // ---- closed?  duplicates inside the batch: the earlier one wins; then the closed set (lanes with s == 0) ----
@@ -779,6 +786,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         const bool nvalid = lane < 32 && ((vm >> node) & 1u);
         const bool want_jump = nvalid && jump0, want_diag = nvalid && diag0;
         int run = 0;
+        uint32_t nflags = 0;
         DBG_MARK(2)
         // ---- jumps.  The successor lanes post their jobs (x | y << 12 | s << 24) in LDS, diagonal ones in slots 0..15 and
         //      straight ones in 16..23, in lane order; the scan lanes and the cell-test lanes pick them up. ----
@@ -817,13 +825,14 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
             const auto m0 = vw.line(b_act ? jl : -1), mP = vw.line(b_act ? jl + 1 : -1), mM = vw.line(b_act ? jl - 1 : -1);
             const auto r0 = Vrow.line(a_act ? acy : -1), ra = Vrow.line(a_act ? acy + aody : -1), rb = Vrow.line(a_act ? acy - aody : -1);
             DBG_MARK(8)
-            bool cblk = false, cstop = false;
+            bool cblk = false, cstop = false, cf1 = false, cf2 = false;
             {
                 // five independent reads, combined without short-circuits: one wait for all of them, no branches
                 const bool b0 = cell_blocked_m(Vrow, r0, acx), b1 = cell_blocked_m(Vrow, r0, acx - aodx), b2 = cell_blocked_m(Vrow, ra, acx - aodx);
                 const bool b3 = cell_blocked_m(Vrow, rb, acx), b4 = cell_blocked_m(Vrow, rb, acx + aodx);
-                const bool forced = (b1 & !b2) | (b3 & !b4);
-                cstop = a_act & (b0 | ((acx == gx) & (acy == gy)) | forced);
+                cf1 = a_act & b1 & !b2;            // forced: the cell beside (against the x travel) is blocked, the one diagonally past it free
+                cf2 = a_act & b3 & !b4;            // forced: the cell beside (against the y travel) is blocked, the one diagonally past it free
+                cstop = a_act & (b0 | ((acx == gx) & (acy == gy)) | cf1 | cf2);
                 cblk = b0 & a_act;
             }
             DBG_MARK(9)
@@ -836,18 +845,30 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
             // -- results.  Diagonal job j of the round: the first cell k with a cell-test stop (bits j*8 + k-1 of the test ballot)
             //    or a scan hit (bits j*7 + k-1 of the horizontal / 28 + j*7 + k-1 of the vertical half of the scan ballot) ends
             //    the jump; every owner lane works its own job out of the three wave-uniform masks. --
+            //    What the new node will need for its own successor rules goes with it (nflags, see the rules above): for the cell a
+            //    diagonal jump ends at, the two forced tests of that cell and whether the next cell of the diagonal is blocked; for
+            //    the end of a straight jump, the sides its stop was forced from.
             const unsigned long long am = wave_ballot(cstop), kb = wave_ballot(cblk), sb = wave_ballot(is_dscan && r > 0);
+            const unsigned long long f1b = wave_ballot(cf1), f2b = wave_ballot(cf2);
             if (want_diag && (my_dc >> 2) == rnd) {
                 const int j = my_dc & 3;
                 const unsigned ta = (unsigned)(am >> (8 * j)) & 0xFFu, tk = (unsigned)(kb >> (8 * j)) & 0xFFu;
                 const unsigned sc = ((unsigned)(sb >> (7 * j)) | (unsigned)(sb >> (28 + 7 * j))) & 0x7Fu;
                 const unsigned any = ta | sc;
-                int drun = kDiagK;
-                if (any) { const int k1 = __ffs((int)any) - 1; drun = ((tk >> k1) & 1u) ? 0 : k1 + 1; }
-                run = drun;
+                const int k1 = any ? __ffs((int)any) - 1 : kDiagK - 1;                  // the cell the jump ends at (0-based)
+                run = ((tk >> k1) & 1u) ? 0 : k1 + 1;
+                const unsigned t1 = ((unsigned)(f1b >> (8 * j)) >> k1) & 1u, t2 = ((unsigned)(f2b >> (8 * j)) >> k1) & 1u;
+                const unsigned ahead_blk = (tk >> (k1 + 1)) & 1u;                       // (cell 9 is not tested: 0, the jump from there will tell)
+                const bool ccw_is_1 = s == 1 || s == 5;                                 // which of the two tests opens the diagonal s + 2
+                nflags = (ccw_is_1 ? t1 : t2) * kEntryForcedA | (ccw_is_1 ? t2 : t1) * kEntryForcedB | ahead_blk * kEntryAheadBlocked;
             }
             const int from_s = __shfl(r, 56 + (my_sj & 7), 64);
-            if (rnd == 0 && want_jump) run = from_s;
+            if (rnd == 0 && want_jump) {
+                run = from_s & 0xFFF;
+                const unsigned fP = ((unsigned)from_s >> 12) & 1u, fM = ((unsigned)from_s >> 13) & 1u;
+                const bool ccw_is_p = s == 0 || s == 6;                                 // line + 1 lies on the counter-clockwise side of E and S travel
+                nflags = (ccw_is_p ? fP : fM) * kEntryForcedA | (ccw_is_p ? fM : fP) * kEntryForcedB;
+            }
         }
         DBG_MARK(3)
 #ifdef DMPP_DEBUG_SEARCH
@@ -873,7 +894,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
             if (push) {
                 const int slot = n_open + __popc(pm & ((1u << lane) - 1u));
                 L.o_f2[slot] = (uint16_t)(fn >> 1);
-                L.o_ent[slot] = (uint32_t)nx | ((uint32_t)ny << 12) | ((uint32_t)s << 24);
+                L.o_ent[slot] = (uint32_t)nx | ((uint32_t)ny << 12) | ((uint32_t)s << 24) | (nflags << 28);
                 L.o_run[slot] = (uint16_t)run;
             }
             n_open += cnt; live += cnt; n_push += cnt;

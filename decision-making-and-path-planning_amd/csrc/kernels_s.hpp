@@ -709,8 +709,9 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         bool valid = have && s == 0;
         {
             const int c0_ = __builtin_amdgcn_readlane(cell, 0), c1_ = __builtin_amdgcn_readlane(cell, 8), c2_ = __builtin_amdgcn_readlane(cell, 16);
-            if ((node == 1 && cell == c0_) || (node == 2 && (cell == c0_ || cell == c1_)) ||
-                (node == 3 && (cell == c0_ || cell == c1_ || cell == c2_))) valid = false;
+            // (no short-circuits: three compares and lane masks that never change)
+            const bool dup = ((node >= 1) & (cell == c0_)) | ((node >= 2) & (cell == c1_)) | ((node >= 3) & (cell == c2_));
+            valid = valid & !dup;
         }
         uint32_t my_slot = 0;
         if (__builtin_expect(n_exp + DMPP_JPS_BATCH <= kClosedMax, 1)) {

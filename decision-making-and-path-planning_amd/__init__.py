@@ -139,6 +139,7 @@ def load_library(path=None):
     lib.pp_set_state.argtypes = [vp, vp, ci]
     lib.pp_plan_tick.argtypes = [vp]
     lib.pp_sync.argtypes = [vp]
+    lib.pp_device_synchronize.argtypes = [vp]
     lib.pp_get_plan.argtypes = [vp, vp, ci]
     lib.pp_get_state.argtypes = [vp, vp, ci]
     lib.pp_get_grid_out.argtypes = [vp, vp, ci]
@@ -160,6 +161,17 @@ def load_library(path=None):
     lib.pp_device_ptr.restype = vp
     lib.pp_stream.argtypes = [vp]
     lib.pp_stream.restype = vp
+    lib.pp_update_async.argtypes = [vp, ci, vp, vp, vp, ci]
+    lib.pp_fetch_async.argtypes = [vp, vp, vp, C.POINTER(C.c_longlong)]
+    lib.pp_wait_tick.argtypes = [vp, C.c_longlong, C.POINTER(ci)]
+    lib.pp_tick_id.argtypes = [vp]
+    lib.pp_tick_id.restype = C.c_longlong
+    lib.pp_host_alloc.argtypes = [cz]
+    lib.pp_host_alloc.restype = vp
+    lib.pp_host_free.argtypes = [vp]
+    lib.pp_host_free.restype = None
+    lib.pp_host_register.argtypes = [vp, cz]
+    lib.pp_host_unregister.argtypes = [vp]
     if lib.pp_sizeof(17) != C.sizeof(MapDesc):
         raise PlannerError(f"ABI mismatch for MapDesc: C {lib.pp_sizeof(17)} B, binding {C.sizeof(MapDesc)} B")
     for which, dt in enumerate(_SIZEOF_ORDER):
@@ -207,6 +219,45 @@ def gen_scenes(cfg, first_scene, n_scenes, n_obs, junction_every=8):
                              _ptr(sc["mot_pool"]), _ptr(sc["state"])))
     sc["n_obs"] = n_obs
     return sc
+
+
+class _Pinned:
+    """Owner of one pp_host_alloc block (freed when the last numpy view of it goes)."""
+
+    def __init__(self, nbytes):
+        self.lib = load_library()
+        self.ptr = self.lib.pp_host_alloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise PlannerError("pp_host_alloc failed: " + self.lib.pp_last_error().decode())
+        self.buf = (C.c_char * max(int(nbytes), 1)).from_address(self.ptr)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self.lib.pp_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_empty(n, dtype):
+    """numpy array of n records in pinned host memory (pp_host_alloc): what pp_update_async / pp_fetch_async want."""
+    dtype = np.dtype(dtype)
+    owner = _Pinned(n * dtype.itemsize)
+    a = np.frombuffer(owner.buf, dtype=dtype, count=n)      # keeps `owner.buf` (and through it nothing else) alive ...
+    a = a.view(_PinnedArray)
+    a._owner = owner                                          # ... so the owner rides on the array
+    return a
+
+
+class _PinnedArray(np.ndarray):
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+
+def pinned_copy(a):
+    out = pinned_empty(len(a), a.dtype)
+    out[...] = a
+    return out
 
 
 class Planner:
@@ -281,6 +332,35 @@ class Planner:
 
     def sync(self):
         _check(self.lib.pp_sync(self.h))
+
+    # ---- streamed ticks (no host wait) ---------------------------------------------------
+    def update_async(self, scene_in=None, obs_pool=None, mot_pool=None, n_obs_total=None):
+        """pp_update_async: the inputs of the next tick.  Arrays should be pinned (pinned_empty / pinned_copy) and must stay
+        untouched until wait_tick of the tick that adopts them."""
+        if n_obs_total is None:
+            n_obs_total = len(obs_pool) if obs_pool is not None else 0
+        _check(self.lib.pp_update_async(self.h, self.n, _ptr(scene_in), _ptr(obs_pool), _ptr(mot_pool), int(n_obs_total)))
+
+    def fetch_async(self, plan=None, grid=None):
+        """pp_fetch_async of the last enqueued tick into `plan` / `grid` (pinned arrays of self.n records). Returns the tick id."""
+        t = C.c_longlong()
+        _check(self.lib.pp_fetch_async(self.h, _ptr(plan), _ptr(grid), C.byref(t)))
+        return t.value
+
+    def wait_tick(self, tick_id, allow_poisoned=False):
+        """pp_wait_tick: host wait for that tick's downloads. Returns the number of poisoned scenes (raises on any unless allowed)."""
+        bad = C.c_int()
+        rc = self.lib.pp_wait_tick(self.h, tick_id, C.byref(bad))
+        if rc != 0 and not (allow_poisoned and bad.value > 0):
+            _check(rc)
+        return bad.value
+
+    def tick_id(self):
+        return self.lib.pp_tick_id(self.h)
+
+    def device_synchronize(self):
+        """pp_device_synchronize: pp_sync + hipDeviceSynchronize (what torch.cuda.synchronize() does, without torch)."""
+        _check(self.lib.pp_device_synchronize(self.h))
 
     def join(self):
         """pp_join: the handle's stream waits (on the device) for every tick enqueued so far."""

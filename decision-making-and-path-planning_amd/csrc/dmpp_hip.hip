@@ -1,10 +1,13 @@
 // dmpp_hip.hip — the C-ABI of include/dmpp_planner.h over the HIP kernels (gfx950 only).
 //
-// One handle = one device, all device buffers, four streams: the handle's stream (the search chain, high priority; also
-// every copy and stand-alone operator), a second search stream for overlapping searches of odd ticks, and two CU-masked
-// side streams (FRONT: obstacle snapshot, rasterise, Decision, Planning; SCORE: k_score).  pp_plan_tick describes the
+// One handle = one device and all device buffers.  Streams: the handle's stream (copies, stand-alone operators, the whole
+// tick of a small batch), kBuf search streams (stream_m[0] is the handle's stream: the searches of consecutive ticks run
+// side by side, each followed by its own scoring pass), the FRONT stream stream_r (obstacle snapshot, launch order,
+// Decision, Planning: highest priority), stream_s (scoring on its own stream: a measurement knob), and - once streamed
+// ticks are in use (pp_update_async / pp_fetch_async) - one upload and two download streams.  pp_plan_tick describes the
 // launch order and the events between the chains; batches below pipeline_min scenes run on the handle's stream with only
-// Decision + Planning forked beside the grid engine.  Every host-visible call joins the chains first (join_all).
+// Decision + Planning forked beside the grid engine.  pp_set_* / pp_get_* join the chains first (join_all) and wait on
+// the host; the streamed calls never wait on the host (pp_wait_tick waits for one tick's downloads only).
 // Nothing here computes planning results on the host; without a GPU pp_create fails.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -38,6 +41,35 @@ constexpr int kBuf = 3;
 // The obstacle snapshot exists 2 * kBuf times: the front chain of tick t writes its snapshot while the scoring pass of tick
 // t - kBuf still reads its own, so that chain need not wait for that pass (only for the search before it, see pp_plan_tick).
 constexpr int kObs = 2 * kBuf;
+// Streamed ticks (pp_update_async / pp_fetch_async): the per-tick inputs - SceneIn records, obstacle pool, motion pool - exist
+// kIn times.  An update is copied into the set after the current one while the ticks in flight still read theirs (a search
+// runs up to kBuf ticks behind the front chain of its tick); a set is written again only after every kernel of the ticks that
+// read it (TickRec) has finished.  PlanOut exists kPlan times, so that Planning(t + 1) does not wait for the download of tick t.
+constexpr int kIn = 12;
+constexpr int kPlan = 12;
+constexpr int kGout = 12;          // GridOut sets: a download is issued when its scoring pass has finished, up to ~8 ticks behind the newest front chain
+constexpr int kDone = 32;          // ticks whose downloads pp_wait_tick can still name
+
+struct InputSet {
+    SceneIn* d_in = nullptr; ObPoint* d_obs = nullptr; ObMotion* d_mot = nullptr;
+    bool have_motion = false; int n_obs_total = 0;
+    hipEvent_t ev_up = nullptr; bool up_recorded = false;
+};
+// one tick in flight: which input set it reads, and the events that close its front chain and its last kernel
+struct TickRec { long long tick; int in_set; hipEvent_t ev_front, ev_tail; };
+// A download asked for by pp_fetch_async.  Its copies are ISSUED only once the kernels they follow have finished (polled by
+// every streamed call; forced by pp_wait_tick and by the tick that is about to overwrite the device set): a copy command
+// enqueued behind an unfinished dependency sits at the head of its hardware queue / DMA queue as a blocked barrier, and
+// streams that share that queue - there are more HIP streams here than hardware queues - stall behind it (measured: the
+// front chain's kernels took 2 - 6 times as long with the GridOut copy of each tick enqueued three ticks ahead of its
+// scoring pass).
+struct PendingFetch {
+    long long tick; int slot;
+    PlanOut* plan_dst; const PlanOut* plan_src; int plan_set; bool plan_issued;
+    GridOut* grid_dst; const GridOut* grid_src; int grid_set; bool grid_issued;
+    hipEvent_t ev_front, ev_tail;      // own references: taken out of the tick's TickRec so that they are not recycled early
+    size_t n;
+};
 
 }  // namespace
 
@@ -52,7 +84,7 @@ struct pp_planner {
     ObPoint* d_obs = nullptr; ObMotion* d_mot = nullptr; ObPoint* d_obs_now[kObs] = {};
     bool have_motion = false;
     // state / outputs
-    SceneState* d_state = nullptr; PlanOut* d_plan = nullptr; GridOut* d_gout[kBuf] = {};
+    SceneState* d_state = nullptr; PlanOut* d_plan = nullptr; GridOut* d_gout[kGout] = {}; int gout_set = 0;   // GridOut: kGout sets (a download of tick t must not hold up the search of tick t + kBuf); gout_set: the last grid tick's
     GlobalPoint2D* d_dec_ref = nullptr;
     // grid engine
     uint8_t* d_grid = nullptr; uint16_t* d_pinfo[kBuf] = {}; uint32_t* d_closed[kBuf] = {};
@@ -89,6 +121,19 @@ struct pp_planner {
     int* d_map_bad = nullptr; int map_roads = 0, map_lanes = 0, map_junctions = 0; bool have_map = false;
     // op scratch (stand-alone operators)
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
+    // streamed ticks (allocated by the first pp_update_async / pp_fetch_async)
+    bool streaming = false;
+    InputSet in_sets[kIn]; int in_cur = 0, in_staged = -1;       // d_in / d_obs / d_mot / have_motion / n_obs_total alias in_sets[in_cur]
+    int resident_mode = 0;       // 0: scenes with their own slices (pp_set_scenes), 1: egos on the resident map (pp_set_egos)
+    PlanOut* d_plan_ring[kPlan] = {}; int plan_cur = 0;          // d_plan aliases d_plan_ring[plan_cur]
+    hipStream_t stream_up = nullptr, stream_dp = nullptr, stream_dg = nullptr;   // upload; download of PlanOut; download of GridOut
+    hipEvent_t ev_fetched_plan[kPlan] = {}, ev_fetched_grid[kGout] = {}; bool fetched_plan_rec[kPlan] = {}, fetched_grid_rec[kGout] = {};
+    hipEvent_t ev_done_p[kDone] = {}, ev_done_g[kDone] = {}; long long done_tick[kDone]; bool done_p_rec[kDone] = {}, done_g_rec[kDone] = {};
+    int32_t* h_bad = nullptr;    // pinned, [kDone]: poisoned scenes of the tick (copied down with its PlanOut)
+    long long tick_seq = 0;      // ticks enqueued so far on this handle (the id of the last one)
+    TickRec last_rec = { -1, 0, nullptr, nullptr };
+    std::vector<TickRec> inflight; std::vector<hipEvent_t> sync_events;   // sync_events: a pool of timing-disabled events
+    std::vector<PendingFetch> fetches;
     // profiling
     int profile = 0;             // 0 off, 1 every kernel of a tick between HIP events, 2 only the search kernel
     std::vector<EvPair> pending; std::vector<hipEvent_t> free_events;
@@ -125,6 +170,87 @@ hipEvent_t get_event(pp_planner* h)
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
+}
+
+// timing-disabled events for cross-stream ordering, pooled
+hipEvent_t get_sync_event(pp_planner* h)
+{
+    if (!h->sync_events.empty()) { hipEvent_t e = h->sync_events.back(); h->sync_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+
+// h->d_in / d_obs / d_mot / have_motion / n_obs_total are the input set the next tick reads
+void adopt_input_set(pp_planner* h, int s)
+{
+    const InputSet& I = h->in_sets[s];
+    h->in_cur = s; h->d_in = I.d_in; h->d_obs = I.d_obs; h->d_mot = I.d_mot; h->have_motion = I.have_motion; h->n_obs_total = I.n_obs_total;
+}
+void note_current_set(pp_planner* h)          // after a pp_set_* call changed what the current set holds
+{
+    InputSet& I = h->in_sets[h->in_cur];
+    I.have_motion = h->have_motion; I.n_obs_total = h->n_obs_total;
+    h->in_staged = -1;                        // an update staged before it is superseded
+}
+
+// Issues the copies of the pending downloads whose kernels have finished.  force_tick: that tick's copies are issued whatever
+// the state of its kernels (behind a stream wait); force_plan_set / force_grid_set: likewise the copies that read that
+// PlanOut / GridOut set (the next tick is about to overwrite it).
+int pump_fetches(pp_planner* h, long long force_tick = -1, int force_plan_set = -1, int force_grid_set = -1)
+{
+    for (PendingFetch& f : h->fetches) {
+        if (f.plan_dst && !f.plan_issued) {
+            const bool ready = hipEventQuery(f.ev_front) == hipSuccess;
+            if (ready || f.tick == force_tick || f.plan_set == force_plan_set) {
+                (void)hipGetLastError();
+                if (!ready) HIP_TRY(hipStreamWaitEvent(h->stream_dp, f.ev_front, 0));
+                HIP_TRY(hipMemcpyAsync(f.plan_dst, f.plan_src, f.n * sizeof(PlanOut), hipMemcpyDefault, h->stream_dp));
+                HIP_TRY(hipEventRecord(h->ev_fetched_plan[f.plan_set], h->stream_dp)); h->fetched_plan_rec[f.plan_set] = true;
+                HIP_TRY(hipEventRecord(h->ev_done_p[f.slot], h->stream_dp));
+                f.plan_issued = true;
+            }
+        }
+        if (f.grid_dst && !f.grid_issued) {
+            hipEvent_t dep = f.ev_tail ? f.ev_tail : f.ev_front;
+            const bool ready = hipEventQuery(dep) == hipSuccess;
+            if (ready || f.tick == force_tick || f.grid_set == force_grid_set) {
+                (void)hipGetLastError();
+                if (!ready) HIP_TRY(hipStreamWaitEvent(h->stream_dg, dep, 0));
+                HIP_TRY(hipMemcpyAsync(f.grid_dst, f.grid_src, f.n * sizeof(GridOut), hipMemcpyDefault, h->stream_dg));
+                HIP_TRY(hipEventRecord(h->ev_fetched_grid[f.grid_set], h->stream_dg)); h->fetched_grid_rec[f.grid_set] = true;
+                HIP_TRY(hipEventRecord(h->ev_done_g[f.slot], h->stream_dg));
+                f.grid_issued = true;
+            }
+        }
+    }
+    (void)hipGetLastError();                  // hipErrorNotReady is not an error here
+    size_t k = 0;                             // completed requests leave from the front (prune_inflight looks at the first one left)
+    while (k < h->fetches.size() && (!h->fetches[k].plan_dst || h->fetches[k].plan_issued) && (!h->fetches[k].grid_dst || h->fetches[k].grid_issued)) k++;
+    h->fetches.erase(h->fetches.begin(), h->fetches.begin() + (long)k);
+    return PP_OK;
+}
+
+// ticks whose kernels have all finished leave the in-flight list (oldest first; the list stays short: a tick's front chain
+// waits for the scoring pass 2 * kBuf ticks before it).  Their events go back to the pool: last_rec may still name the
+// events of the last tick, which are recorded again by the next tick at the earliest - and then last_rec names that one.
+int prune_inflight(pp_planner* h)
+{
+    size_t k = 0;
+    while (k < h->inflight.size()) {
+        const TickRec& r = h->inflight[k];
+        if (!h->fetches.empty() && r.tick >= h->fetches.front().tick) break;      // its events are still named by a download not issued yet
+        if (hipEventQuery(r.ev_front) != hipSuccess || (r.ev_tail && hipEventQuery(r.ev_tail) != hipSuccess)) break;
+        h->sync_events.push_back(r.ev_front); if (r.ev_tail) h->sync_events.push_back(r.ev_tail);
+        k++;
+    }
+    (void)hipGetLastError();                  // hipErrorNotReady is not an error here
+    h->inflight.erase(h->inflight.begin(), h->inflight.begin() + (long)k);
+    if (h->inflight.size() > 256) {           // a caller that never lets the device catch up: wait for the oldest
+        HIP_TRY(hipEventSynchronize(h->inflight.front().ev_front));
+        if (h->inflight.front().ev_tail) HIP_TRY(hipEventSynchronize(h->inflight.front().ev_tail));
+    }
+    return PP_OK;
 }
 
 constexpr int kScoreWideMaxScenes = 128;     // up to here k_score runs 16 waves per scene (one scene per CU at most)
@@ -294,21 +420,27 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     for (int q = 0; q < kObs; q++)
         if (hipEventCreateWithFlags(&h->ev_score[q], hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
     const size_t ns = (size_t)caps->max_scenes;
-    if ((r = dmalloc(&h->d_in, ns))) return bail(r);
+    if ((r = dmalloc(&h->in_sets[0].d_in, ns))) return bail(r);
+    h->d_in = h->in_sets[0].d_in;
     if ((r = dmalloc(&h->d_lane, (size_t)caps->max_lane_pts_total))) return bail(r);
     if ((r = dmalloc(&h->d_attr, (size_t)caps->max_lane_pts_total + 1))) return bail(r);
     if ((r = dmalloc(&h->d_ref, (size_t)caps->max_ref_pts_total))) return bail(r);
-    if ((r = dmalloc(&h->d_obs, (size_t)caps->max_obs_total))) return bail(r);
-    if ((r = dmalloc(&h->d_mot, (size_t)caps->max_obs_total))) return bail(r);
+    if ((r = dmalloc(&h->in_sets[0].d_obs, (size_t)caps->max_obs_total))) return bail(r);
+    h->d_obs = h->in_sets[0].d_obs;
+    if ((r = dmalloc(&h->in_sets[0].d_mot, (size_t)caps->max_obs_total))) return bail(r);
+    h->d_mot = h->in_sets[0].d_mot;
     if (hipMemsetAsync(h->d_mot, 0, (size_t)(caps->max_obs_total > 0 ? caps->max_obs_total : 1) * sizeof(ObMotion), h->stream) != hipSuccess)
         return bail(fail(PP_ERR_HIP, "memset failed"));     // velocities nobody uploaded are zero, never uninitialised
     if ((r = dmalloc(&h->d_bad, (size_t)1))) return bail(r);
     for (int q = 0; q < kObs; q++) if ((r = dmalloc(&h->d_obs_now[q], (size_t)caps->max_obs_total))) return bail(r);
     if ((r = dmalloc(&h->d_state, ns))) return bail(r);
-    if ((r = dmalloc(&h->d_plan, ns))) return bail(r);
-    for (int q = 0; q < kBuf; q++) if ((r = dmalloc(&h->d_gout[q], ns))) return bail(r);
+    if ((r = dmalloc(&h->d_plan_ring[0], ns))) return bail(r);
+    h->d_plan = h->d_plan_ring[0];
+    if (hipMemsetAsync(h->d_plan, 0, ns * sizeof(PlanOut), h->stream) != hipSuccess) return bail(fail(PP_ERR_HIP, "memset failed"));
+    for (int q = 0; q < kDone; q++) h->done_tick[q] = -1;
+    for (int q = 0; q < kGout; q++) if ((r = dmalloc(&h->d_gout[q], ns))) return bail(r);
     if ((r = dmalloc(&h->d_dec_ref, ns * DMPP_MAX_REFPATH))) return bail(r);
-    for (int q = 0; q < kBuf; q++)
+    for (int q = 0; q < kGout; q++)
         if (hipMemsetAsync(h->d_gout[q], 0, ns * sizeof(GridOut), h->stream) != hipSuccess) return bail(fail(PP_ERR_HIP, "memset failed"));
     if (cfg->grid_stage) {
         h->grid_cells = (size_t)cfg->grid_w * cfg->grid_h;
@@ -338,13 +470,25 @@ int pp_destroy(pp_handle h)
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     if (h->stream_s) (void)hipStreamSynchronize(h->stream_s);
+    for (hipStream_t st : { h->stream_up, h->stream_dp, h->stream_dg }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (int q = 0; q < kObs; q++) if (h->d_obs_now[q]) (void)hipFree(h->d_obs_now[q]);
-    void* bufs[] = { h->d_in, h->d_lane, h->d_attr, h->d_ref, h->d_obs, h->d_mot, h->d_state, h->d_plan,
+    for (int q = 0; q < kIn; q++) {
+        InputSet& I = h->in_sets[q];
+        for (void* b : { (void*)I.d_in, (void*)I.d_obs, (void*)I.d_mot }) if (b) (void)hipFree(b);
+        if (I.ev_up) (void)hipEventDestroy(I.ev_up);
+    }
+    for (int q = 0; q < kPlan; q++) { if (h->d_plan_ring[q]) (void)hipFree(h->d_plan_ring[q]); if (h->ev_fetched_plan[q]) (void)hipEventDestroy(h->ev_fetched_plan[q]); }
+    for (int q = 0; q < kGout; q++) { if (h->ev_fetched_grid[q]) (void)hipEventDestroy(h->ev_fetched_grid[q]); if (h->d_gout[q]) (void)hipFree(h->d_gout[q]); }
+    for (int q = 0; q < kDone; q++) { if (h->ev_done_p[q]) (void)hipEventDestroy(h->ev_done_p[q]); if (h->ev_done_g[q]) (void)hipEventDestroy(h->ev_done_g[q]); }
+    for (auto e : h->sync_events) (void)hipEventDestroy(e);
+    for (auto& r : h->inflight) { (void)hipEventDestroy(r.ev_front); if (r.ev_tail) (void)hipEventDestroy(r.ev_tail); }
+    if (h->h_bad) (void)hipHostFree(h->h_bad);
+    void* bufs[] = { h->d_lane, h->d_attr, h->d_ref, h->d_state,
                      h->d_dec_ref, h->d_grid, h->d_scratch, h->d_map_first, h->d_map_lanes, h->d_map_width, h->d_map_junc, h->d_map_bad, h->d_bad,
                      h->d_gridbad };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int q = 0; q < kBuf; q++)
-        for (void* b : { (void*)h->d_gout[q], (void*)h->d_pinfo[q], (void*)h->d_closed[q], (void*)h->d_order[q], (void*)h->d_path[q],
+        for (void* b : { (void*)h->d_pinfo[q], (void*)h->d_closed[q], (void*)h->d_order[q], (void*)h->d_path[q],
                          (void*)h->d_gbm[q], (void*)h->d_perm[q], (void*)h->d_cost[q], (void*)h->d_ovf[q], (void*)h->d_need[q] })
             if (b) (void)hipFree(b);
     for (int q = 0; q < kBuf; q++) if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]);
@@ -422,6 +566,7 @@ int pp_set_scenes(pp_handle h, int n_scenes, const SceneIn* in, const GlobalPoin
         h->have_motion = true;
     }
     h->n_scenes = n_scenes; h->n_obs_total = n_obs_total; h->n_lane_pts = n_lane_pts; h->n_ref_pts = n_ref_pts;
+    h->resident_mode = 0; note_current_set(h);
     return validate_resident(h, n_scenes, "pp_set_scenes");     // syncs: the caller may reuse its buffers
 }
 
@@ -500,6 +645,7 @@ int pp_set_egos(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs
     HIP_TRY(hipMemcpyAsync(&bad, h->d_map_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->n_scenes = n_scenes; h->n_obs_total = n_obs_total;
+    h->resident_mode = 1; note_current_set(h);
     if (bad) { h->n_scenes = 0; return fail(PP_ERR_ARG, "pp_set_egos: " + std::to_string(bad) + " scene(s) name a road or lane outside the map"); }
     return validate_resident(h, n_scenes, "pp_set_egos");       // the obstacle slices are still the caller's
 }
@@ -522,6 +668,7 @@ int pp_set_n_scenes(pp_handle h, int n_scenes, int n_lane_pts, int n_ref_pts, in
     { int r = join_all(h); if (r) return r; }
     h->n_scenes = n_scenes; h->n_obs_total = n_obs_total; h->n_lane_pts = n_lane_pts; h->n_ref_pts = n_ref_pts;
     h->have_motion = have_motion != 0; h->have_attr = have_lane_attr != 0;
+    h->resident_mode = 0; note_current_set(h);
     return validate_resident(h, n_scenes, "pp_set_n_scenes");
 }
 
@@ -553,8 +700,20 @@ int pp_plan_tick(pp_handle h)
     //   search(t) waits for the snapshot of front(t) and for score(t-2) [path / GridOut p];  score(t) waits for search(t).
     // Small batches and ticks without the grid stage stay on one stream (a cross-stream hand-over costs tens of
     // microseconds; only Decision + Planning run beside the grid engine there).
-    const int p = (h->parity + 1) % kBuf, p_prev = h->parity;
+    // (a tick without the grid stage leaves the search buffers alone: pp_get_grid_out / pp_get_path keep returning the last search)
+    const int p = c.grid_stage ? (h->parity + 1) % kBuf : h->parity, p_prev = h->parity;
+    const int gs = c.grid_stage ? (h->gout_set + 1) % kGout : h->gout_set;
     const bool piped = c.grid_stage && n >= h->pipeline_min;
+    // streamed inputs: the update staged by pp_update_async becomes the set this tick (and the following ones) read
+    bool adopted = false;
+    if (h->in_staged >= 0) { adopt_input_set(h, h->in_staged); h->in_staged = -1; adopted = true; }
+    if (h->streaming) {
+        // downloads whose kernels have finished are issued now; one that still reads a set this tick overwrites is issued whatever
+        int r = pump_fetches(h, -1, (h->plan_cur + 1) % kPlan, c.grid_stage ? (h->gout_set + 1) % kGout : -1); if (r) return r;
+        r = prune_inflight(h); if (r) return r;
+        h->plan_cur = (h->plan_cur + 1) % kPlan; h->d_plan = h->d_plan_ring[h->plan_cur];
+        if (!adopted) h->h_bad[(h->tick_seq + 1) % kDone] = 0;
+    }
     if (c.grid_stage && !h->search_force_gbm) {
         // LDS budget of the search (data words per view).  First tick: from the obstacle density; afterwards from what the
         // densest scene of an earlier tick needed (+ 1/8): the scoring pass behind each search stores it in pinned memory, which
@@ -605,6 +764,10 @@ int pp_plan_tick(pp_handle h)
         HIP_TRY(hipEventRecord(h->ev_fork, h->stream)); HIP_TRY(hipStreamWaitEvent(sf, h->ev_fork, 0));
     }
     h->r_on_main = sr == h->stream;
+    // (an event that has completed needs no barrier packet on the front chain: uploads and downloads run ticks ahead / behind)
+    auto wait_unless_done = [](hipStream_t st, hipEvent_t e) { if (hipEventQuery(e) == hipSuccess) return hipSuccess; (void)hipGetLastError(); return hipStreamWaitEvent(st, e, 0); };
+    if (adopted && h->in_sets[h->in_cur].up_recorded) HIP_TRY(wait_unless_done(sf, h->in_sets[h->in_cur].ev_up));   // every kernel of the tick follows the snapshot kernel
+    if (h->streaming && h->fetched_plan_rec[h->plan_cur]) HIP_TRY(wait_unless_done(sr, h->ev_fetched_plan[h->plan_cur]));   // PlanOut set still being downloaded (kPlan ticks ago)
     ObPoint* obs_now = h->d_obs_now[po];
     {
         Timed t(h, PP_K_OBSTACLES, sf);
@@ -632,6 +795,7 @@ int pp_plan_tick(pp_handle h)
     if (sr != h->stream) { HIP_TRY(hipEventRecord(h->ev_join, sr)); h->front_recorded = true; h->front_unjoined = piped; }
     if (c.grid_stage) {
         if (sf != sm) HIP_TRY(hipStreamWaitEvent(sm, h->ev_raster, 0));
+        if (h->streaming && h->fetched_grid_rec[gs]) HIP_TRY(wait_unless_done(sm, h->ev_fetched_grid[gs]));   // GridOut set still being downloaded (kGout grid ticks ago)
         const int32_t* perm = order_scenes ? h->d_perm[p] : nullptr;
         if (perm && !order_in_front)          // one-stream tick with more scenes than search slots (DMPP_PIPELINE_MIN raised): keyed by the previous tick
             hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[p_prev], h->d_perm[p]);
@@ -645,10 +809,10 @@ int pp_plan_tick(pp_handle h)
 #define DMPP_LAUNCH_SEARCH(K)                                                                                                                  \
                 case K:                                                                                                                        \
                     if (wide) hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWavesWide>), dim3(n), dim3(dmpp::kSearchSetupWavesWide * DMPP_WAVE), dyn, sm, c, n, h->caps.order_cap, budget, perm, \
-                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], \
+                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[gs], h->d_gbm[p], \
                                            h->d_cost[p], h->d_ovf[p], h->d_need[p]);                                                         \
                     else hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWaves>), dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget, perm,  \
-                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[p], h->d_gbm[p], \
+                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[gs], h->d_gbm[p], \
                                            h->d_cost[p], h->d_ovf[p], h->d_need[p]);                                                         \
                     break;
                 DMPP_LAUNCH_SEARCH(0) DMPP_LAUNCH_SEARCH(1) DMPP_LAUNCH_SEARCH(2)
@@ -663,16 +827,24 @@ int pp_plan_tick(pp_handle h)
             int32_t* need_host = (!h->lds_budget_fixed && !h->search_force_gbm) ? &h->h_need[p] : nullptr;
             if (n <= kScoreWideMaxScenes)     // few scenes: sixteen waves per scene (17 candidates in two rounds)
                 hipLaunchKernelGGL(dmpp::k_score<16>, dim3(n), dim3(16 * DMPP_WAVE), sizeof(dmpp::ScoreShared<16>), ss, c, n, h->d_in, obs_now,
-                                   h->d_path[p], h->d_gout[p], h->d_need[p], need_host);
+                                   h->d_path[p], h->d_gout[gs], h->d_need[p], need_host);
             else
                 hipLaunchKernelGGL(dmpp::k_score<4>, dim3(n), dim3(4 * DMPP_WAVE), sizeof(dmpp::ScoreShared<4>), ss, c, n, h->d_in, obs_now,
-                                   h->d_path[p], h->d_gout[p], h->d_need[p], need_host);
+                                   h->d_path[p], h->d_gout[gs], h->d_need[p], need_host);
         }
         h->score_recorded[po] = piped;
         if (piped) HIP_TRY(hipEventRecord(h->ev_score[po], ss));
         if (!piped && sr != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));   // one-stream mode: the tick is complete on the handle's stream
     }
-    h->parity = p; h->obs_set = po;
+    h->parity = p; h->obs_set = po; h->gout_set = gs;
+    h->tick_seq++;
+    if (h->streaming) {          // what a later update of this tick's input set, and a download of its results, wait for
+        TickRec rec = { h->tick_seq, h->in_cur, get_sync_event(h), c.grid_stage ? get_sync_event(h) : nullptr };
+        if (!rec.ev_front || (c.grid_stage && !rec.ev_tail)) return fail(PP_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(rec.ev_front, sr));
+        if (rec.ev_tail) HIP_TRY(hipEventRecord(rec.ev_tail, piped ? ss : h->stream));
+        h->inflight.push_back(rec); h->last_rec = rec;
+    }
     HIP_TRY(hipGetLastError());
     return PP_OK;
 }
@@ -690,6 +862,19 @@ int pp_sync(pp_handle h)
     HIP_TRY(hipSetDevice(h->device));
     { int r = join_all(h); if (r) return r; }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->streaming) {          // staged updates and downloads too (everything has finished: every pending copy is issued)
+        int r = pump_fetches(h); if (r) return r;
+        for (hipStream_t st : { h->stream_up, h->stream_dp, h->stream_dg }) HIP_TRY(hipStreamSynchronize(st));
+    }
+    return PP_OK;
+}
+
+int pp_device_synchronize(pp_handle h)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    { int r = pp_sync(h); if (r) return r; }
+    HIP_TRY(hipDeviceSynchronize());
     return PP_OK;
 }
 
@@ -718,7 +903,7 @@ int pp_get_grid_out(pp_handle h, GridOut* out, int n)
 {
     if (!h || !out) return fail(PP_ERR_ARG, "null argument");
     if (n < 0 || n > h->n_scenes) return fail(PP_ERR_ARG, "n exceeds the resident scenes");
-    return fetch(h, out, h->d_gout[h->parity], (size_t)n * sizeof(GridOut));
+    return fetch(h, out, h->d_gout[h->gout_set], (size_t)n * sizeof(GridOut));
 }
 int pp_get_grid(pp_handle h, int scene, uint8_t* grid)
 {
@@ -804,6 +989,177 @@ int pp_plan_tick_batch(pp_handle h, int n_scenes, const SceneIn* in, const ObPoi
     if (grid_out && h->cfg.grid_stage && (r = pp_get_grid_out(h, grid_out, n_scenes))) return r;
     return PP_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Streamed ticks: new inputs every tick, results out every tick, no host wait in between.
+// The reference reads its blackboard at the top of every tick (Planning.cpp:95-112, Decision.cpp:155-160) and publishes at
+// the end of it (Planning.cpp:186,214; Decision.cpp:203).
+
+static int ensure_streaming(pp_handle h)
+{
+    if (h->streaming) return PP_OK;
+    const size_t ns = (size_t)h->caps.max_scenes, no = (size_t)(h->caps.max_obs_total > 0 ? h->caps.max_obs_total : 1);
+    int r;
+    for (int q = 0; q < kIn; q++) {
+        InputSet& I = h->in_sets[q];
+        if (!I.d_in && (r = dmalloc(&I.d_in, ns))) return r;
+        if (!I.d_obs && (r = dmalloc(&I.d_obs, no))) return r;
+        if (!I.d_mot) { if ((r = dmalloc(&I.d_mot, no))) return r; HIP_TRY(hipMemsetAsync(I.d_mot, 0, no * sizeof(ObMotion), h->stream)); }
+        if (!I.ev_up) HIP_TRY(hipEventCreateWithFlags(&I.ev_up, hipEventDisableTiming));
+    }
+    for (int q = 1; q < kPlan; q++) if (!h->d_plan_ring[q]) {
+        if ((r = dmalloc(&h->d_plan_ring[q], ns))) return r;
+        HIP_TRY(hipMemsetAsync(h->d_plan_ring[q], 0, ns * sizeof(PlanOut), h->stream));
+    }
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    // the upload carries two small kernels (map views, slice check) that the next front chain waits for: top priority
+    if (!h->stream_up) HIP_TRY(hipStreamCreateWithPriority(&h->stream_up, hipStreamNonBlocking, prio_greatest));
+    if (!h->stream_dp) HIP_TRY(hipStreamCreateWithPriority(&h->stream_dp, hipStreamNonBlocking, prio_least));
+    if (!h->stream_dg) HIP_TRY(hipStreamCreateWithPriority(&h->stream_dg, hipStreamNonBlocking, prio_least));
+    for (int q = 0; q < kPlan; q++) if (!h->ev_fetched_plan[q]) HIP_TRY(hipEventCreateWithFlags(&h->ev_fetched_plan[q], hipEventDisableTiming));
+    for (int q = 0; q < kGout; q++) if (!h->ev_fetched_grid[q]) HIP_TRY(hipEventCreateWithFlags(&h->ev_fetched_grid[q], hipEventDisableTiming));
+    for (int q = 0; q < kDone; q++) {
+        if (!h->ev_done_p[q]) HIP_TRY(hipEventCreateWithFlags(&h->ev_done_p[q], hipEventDisableTiming));
+        if (!h->ev_done_g[q]) HIP_TRY(hipEventCreateWithFlags(&h->ev_done_g[q], hipEventDisableTiming));
+    }
+    if (!h->h_bad) { HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_bad), kDone * sizeof(int32_t), hipHostMallocDefault)); for (int q = 0; q < kDone; q++) h->h_bad[q] = 0; }
+    // everything enqueued before streaming began (ticks, the memsets above) is ordered before the three new streams
+    { int r2 = join_all(h); if (r2) return r2; }
+    hipEvent_t e = get_sync_event(h);
+    if (!e) return fail(PP_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(e, h->stream));
+    for (hipStream_t st : { h->stream_up, h->stream_dp, h->stream_dg }) HIP_TRY(hipStreamWaitEvent(st, e, 0));
+    HIP_TRY(hipStreamSynchronize(h->stream));      // (once per handle) so that e can go back to the pool
+    h->sync_events.push_back(e);
+    h->streaming = true;
+    return PP_OK;
+}
+
+int pp_update_async(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    if (n_scenes <= 0 || n_scenes != h->n_scenes)
+        return fail(PP_ERR_STATE, "pp_update_async replaces the per-tick inputs of the resident scenes: n_scenes must be the resident count (pp_set_scenes / pp_set_egos come first)");
+    if (!in && !obs_pool) return fail(PP_ERR_ARG, "nothing to update");
+    if (obs_pool && (n_obs_total < 0 || n_obs_total > h->caps.max_obs_total)) return fail(PP_ERR_CAPACITY, "obstacle pool larger than caps.max_obs_total");
+    if (!obs_pool && mot_pool) return fail(PP_ERR_ARG, "a motion pool without its obstacle pool");
+    HIP_TRY(hipSetDevice(h->device));
+    { int r = ensure_streaming(h); if (r) return r; }
+    { int r = pump_fetches(h); if (r) return r; }
+    { int r = prune_inflight(h); if (r) return r; }
+    const InputSet& C = h->in_sets[h->in_cur];
+    const int s = h->in_staged >= 0 ? h->in_staged : (h->in_cur + 1) % kIn;
+    // what the update leaves alone is carried over from the set it replaces (the staged one if there is one)
+    const InputSet& P = h->in_staged >= 0 ? h->in_sets[h->in_staged] : C;
+    InputSet& I = h->in_sets[s];
+    hipStream_t su = h->stream_up;
+    for (const TickRec& r : h->inflight) if (r.in_set == s) {      // the ticks that still read set s (a whole ring ago: long finished, as a rule)
+        HIP_TRY(hipStreamWaitEvent(su, r.ev_front, 0));
+        if (r.ev_tail) HIP_TRY(hipStreamWaitEvent(su, r.ev_tail, 0));
+    }
+    const int n = n_scenes;
+    if (in) HIP_TRY(hipMemcpyAsync(I.d_in, in, (size_t)n * sizeof(SceneIn), hipMemcpyDefault, su));
+    else if (&P != &I) HIP_TRY(hipMemcpyAsync(I.d_in, P.d_in, (size_t)n * sizeof(SceneIn), hipMemcpyDeviceToDevice, su));
+    int n_obs = n_obs_total; bool have_motion = false;
+    if (obs_pool) {
+        if (n_obs) HIP_TRY(hipMemcpyAsync(I.d_obs, obs_pool, (size_t)n_obs * sizeof(ObPoint), hipMemcpyDefault, su));
+        if (n_obs && mot_pool) { HIP_TRY(hipMemcpyAsync(I.d_mot, mot_pool, (size_t)n_obs * sizeof(ObMotion), hipMemcpyDefault, su)); have_motion = true; }
+    } else {
+        n_obs = P.n_obs_total; have_motion = P.have_motion;
+        if (&P != &I && n_obs) {
+            HIP_TRY(hipMemcpyAsync(I.d_obs, P.d_obs, (size_t)n_obs * sizeof(ObPoint), hipMemcpyDeviceToDevice, su));
+            if (have_motion) HIP_TRY(hipMemcpyAsync(I.d_mot, P.d_mot, (size_t)n_obs * sizeof(ObMotion), hipMemcpyDeviceToDevice, su));
+        }
+    }
+    // the count of poisoned scenes is written by the two kernels below straight into pinned host memory (the slot of the tick
+    // that will adopt this update; zeroed here by the host: that tick is not enqueued yet, nothing else writes the slot) - no
+    // memset and no copy command on the upload stream
+    int32_t* bad_slot = &h->h_bad[(h->tick_seq + 1) % kDone];
+    if (in || s != h->in_staged) *reinterpret_cast<volatile int32_t*>(bad_slot) = 0;      // (a second, obstacles-only update of a staged set keeps the count of the first)
+    const dim3 grid((unsigned)((n + dmpp::kBlock - 1) / dmpp::kBlock)), block(dmpp::kBlock);
+    if (h->resident_mode == 1 && in)      // egos on the resident map: lane views and junction slices from road / lane numbers
+        hipLaunchKernelGGL(dmpp::k_resolve_map, grid, block, 0, su, n, I.d_in, h->map_roads, h->d_map_first, h->d_map_lanes, h->d_attr, h->d_map_width,
+                           h->map_junctions, h->d_map_junc, bad_slot);
+    hipLaunchKernelGGL(dmpp::k_sanitise_scenes, grid, block, 0, su, n, I.d_in, n_obs, h->n_lane_pts, h->n_ref_pts, bad_slot);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(I.ev_up, su));
+    I.up_recorded = true; I.have_motion = have_motion; I.n_obs_total = n_obs;
+    h->in_staged = s;
+    return PP_OK;
+}
+
+int pp_fetch_async(pp_handle h, PlanOut* plan, GridOut* grid, long long* tick_id)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    if (!plan && !grid) return fail(PP_ERR_ARG, "nothing to fetch");
+    if (h->tick_seq == 0 || h->n_scenes <= 0) return fail(PP_ERR_STATE, "pp_fetch_async: no tick has been enqueued");
+    if (grid && !h->cfg.grid_stage) return fail(PP_ERR_STATE, "pp_fetch_async: the last tick ran without the grid stage");
+    HIP_TRY(hipSetDevice(h->device));
+    { int r = ensure_streaming(h); if (r) return r; }
+    const long long T = h->tick_seq;
+    const int slot = (int)(T % kDone), n = h->n_scenes;
+    if (h->last_rec.tick != T) {
+        // the last tick was enqueued before streaming began: one event behind everything stands in for its two
+        { int r = join_all(h); if (r) return r; }
+        hipEvent_t e = get_sync_event(h);
+        if (!e) return fail(PP_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(e, h->stream));
+        TickRec rec = { T, h->in_cur, e, nullptr };
+        h->inflight.push_back(rec); h->last_rec = rec;
+    }
+    const TickRec& R = h->last_rec;
+    if (h->done_tick[slot] != T) { h->done_tick[slot] = T; h->done_g_rec[slot] = false; h->done_p_rec[slot] = false; }
+    PendingFetch f{};
+    f.tick = T; f.slot = slot; f.n = (size_t)n; f.ev_front = R.ev_front; f.ev_tail = R.ev_tail;
+    if (plan) { f.plan_dst = plan; f.plan_src = h->d_plan; f.plan_set = h->plan_cur; h->done_p_rec[slot] = true; }
+    if (grid) { f.grid_dst = grid; f.grid_src = h->d_gout[h->gout_set]; f.grid_set = h->gout_set; h->done_g_rec[slot] = true; }
+    // a second request for the same tick (PlanOut and GridOut asked for separately) joins the first
+    bool joined = false;
+    for (PendingFetch& g : h->fetches) if (g.tick == T) {
+        if (plan && !g.plan_dst) { g.plan_dst = f.plan_dst; g.plan_src = f.plan_src; g.plan_set = f.plan_set; g.plan_issued = false; joined = true; }
+        if (grid && !g.grid_dst) { g.grid_dst = f.grid_dst; g.grid_src = f.grid_src; g.grid_set = f.grid_set; g.grid_issued = false; joined = true; }
+    }
+    if (!joined) h->fetches.push_back(f);
+    { int r = pump_fetches(h); if (r) return r; }
+    if (tick_id) *tick_id = T;
+    return PP_OK;
+}
+
+long long pp_tick_id(pp_handle h) { return h ? h->tick_seq : -1; }
+
+int pp_wait_tick(pp_handle h, long long tick_id, int* n_poisoned)
+{
+    if (!h) return fail(PP_ERR_ARG, "null handle");
+    if (n_poisoned) *n_poisoned = 0;
+    if (tick_id <= 0 || tick_id > h->tick_seq) return fail(PP_ERR_ARG, "pp_wait_tick: no such tick");
+    const int slot = (int)(tick_id % kDone);
+    if (!h->streaming || h->done_tick[slot] != tick_id)
+        return fail(PP_ERR_ARG, "pp_wait_tick: no pp_fetch_async was issued for that tick (or more than " + std::to_string(kDone) + " ticks ago)");
+    HIP_TRY(hipSetDevice(h->device));
+    { int r = pump_fetches(h, tick_id); if (r) return r; }
+    if (h->done_p_rec[slot]) HIP_TRY(hipEventSynchronize(h->ev_done_p[slot]));
+    if (h->done_g_rec[slot]) HIP_TRY(hipEventSynchronize(h->ev_done_g[slot]));
+    const int bad = (int)reinterpret_cast<volatile int32_t*>(h->h_bad)[slot];
+    if (n_poisoned) *n_poisoned = bad;
+    if (bad) return fail(PP_ERR_ARG, "tick " + std::to_string(tick_id) + ": " + std::to_string(bad) + " scene(s) of its update had a slice outside its pool (or a road / lane outside the map) and ran with empty inputs");
+    return PP_OK;
+}
+
+void* pp_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g_err = "hipHostMalloc failed"; return nullptr; }
+    return p;
+}
+void pp_host_free(void* p) { if (p) (void)hipHostFree(p); }
+int pp_host_register(void* p, size_t bytes)
+{
+    if (!p || !bytes) return fail(PP_ERR_ARG, "null argument");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return PP_OK;
+}
+int pp_host_unregister(void* p) { if (!p) return PP_OK; HIP_TRY(hipHostUnregister(p)); return PP_OK; }
 
 // ---------------------------------------------------------------------------------------
 // stand-alone operators
@@ -1046,7 +1402,7 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes)
     case PP_BUF_MOT_POOL: p = h->d_mot; b = (size_t)h->caps.max_obs_total * sizeof(ObMotion); break;
     case PP_BUF_STATE: p = h->d_state; b = ns * sizeof(SceneState); break;
     case PP_BUF_PLAN_OUT: p = h->d_plan; b = ns * sizeof(PlanOut); break;
-    case PP_BUF_GRID_OUT: p = h->d_gout[h->parity]; b = ns * sizeof(GridOut); break;      // the buffers of the last tick
+    case PP_BUF_GRID_OUT: p = h->d_gout[h->gout_set]; b = ns * sizeof(GridOut); break;      // the buffers of the last tick
     case PP_BUF_GRID: p = nullptr; b = 0; break;      // no occupancy grid is kept after a tick (the search builds it in LDS): use pp_get_grid
     case PP_BUF_PATH: p = h->d_path[h->parity]; b = ns * (size_t)h->max_path0 * 4; break;
     case PP_BUF_LANE_ATTR: p = h->d_attr; b = (size_t)h->caps.max_lane_pts_total; break;

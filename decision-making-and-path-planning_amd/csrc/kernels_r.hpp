@@ -205,7 +205,7 @@ k_resolve_map(int n_scenes, SceneIn* __restrict__ in, int n_roads, const int32_t
             lv.lanechg_attribute = attr[cur.point_off + id];                        // Decision.cpp:566
             lv.lane_width = (double)width_cm[cur.point_off + id] / 100.0;           // Decision.cpp:578
         }
-    } else atomicAdd(bad, 1);
+    } else atomicAdd_system(bad, 1);       // (bad may be pinned host memory: the streamed path)
     si.lanes = lv;
     int roff = 0, rn = 0;
     for (int j = 0; j < n_junctions; j++) {
@@ -231,6 +231,26 @@ k_validate_scenes(int n_scenes, const SceneIn* __restrict__ in, int n_obs_total,
                     inside(si.lanes.left_off, si.lanes.left_n, n_lane_pts) && inside(si.lanes.right_off, si.lanes.right_n, n_lane_pts) &&
                     inside(si.ref_off, si.ref_n, n_ref_pts);
     if (!ok) atomicAdd(bad, 1);
+}
+
+// Streamed updates (pp_update_async) cannot refuse a batch - nobody waits for the answer - so the same test POISONS a scene
+// instead: every slice of a failing scene is made empty (an empty slice is never dereferenced, whatever its offset), the tick
+// runs on it like on a scene without lanes and obstacles, and bad[0] counts it; pp_wait_tick reports the count of that tick.
+__global__ void __launch_bounds__(kBlock)
+k_sanitise_scenes(int n_scenes, SceneIn* __restrict__ in, int n_obs_total, int n_lane_pts, int n_ref_pts, int* __restrict__ bad)
+{
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_scenes) return;
+    SceneIn& si = in[s];
+    auto inside = [](int off, int n, int pool) { return n == 0 || (n > 0 && off >= 0 && (long long)off + n <= (long long)pool); };
+    const bool ok = inside(si.obs_off, si.obs_n, n_obs_total) && inside(si.lanes.cur_off, si.lanes.cur_n, n_lane_pts) &&
+                    inside(si.lanes.left_off, si.lanes.left_n, n_lane_pts) && inside(si.lanes.right_off, si.lanes.right_n, n_lane_pts) &&
+                    inside(si.ref_off, si.ref_n, n_ref_pts);
+    if (!ok) {
+        si.obs_n = 0; si.lanes.cur_n = 0; si.lanes.left_n = 0; si.lanes.right_n = 0; si.ref_n = 0;
+        si.obs_off = 0; si.lanes.cur_off = 0; si.lanes.left_off = 0; si.lanes.right_off = 0; si.ref_off = 0;
+        atomicAdd_system(bad, 1);          // (bad may be pinned host memory: the streamed path)
+    }
 }
 
 // ---------------------------------------------------------------------------------------

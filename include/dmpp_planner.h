@@ -105,8 +105,10 @@ int  pp_get_scene_in(pp_handle h, SceneIn* out, int n_scenes);
 int  pp_plan_tick(pp_handle h);
 /* Makes pp_stream(h) wait, on the device, for every tick enqueued so far; returns at once (no host wait). */
 int  pp_join(pp_handle h);
-/* pp_join + host wait. */
+/* pp_join + host wait (and, once streamed ticks are in use, every staged update and download). */
 int  pp_sync(pp_handle h);
+/* pp_sync + hipDeviceSynchronize: every stream of the handle's device, the caller's included. */
+int  pp_device_synchronize(pp_handle h);
 /* Replaces SetPlanningStatus/SetUdpSendCtrl (Planning.cpp:186,214) and SetDecisionOut (Decision.cpp:203). */
 int  pp_get_plan(pp_handle h, PlanOut* out, int n_scenes);
 int  pp_get_state(pp_handle h, SceneState* state, int n_scenes);
@@ -123,6 +125,44 @@ int  pp_plan_tick_batch(pp_handle h, int n_scenes, const SceneIn* in,
                         const GlobalPoint3D* lane_pool, const uint8_t* lane_attr_pool, int n_lane_pts,
                         const GlobalPoint2D* ref_pool, int n_ref_pts,
                         SceneState* state_inout, PlanOut* out, GridOut* grid_out /* may be NULL */);
+
+/* ---- streamed ticks: new inputs in, results out, every tick, with no host wait in between --------------------------
+ * The reference reads obstacles / location / decision from its blackboard at the top of every tick (Planning.cpp:95-112,
+ * Decision.cpp:155-160) and publishes at the end of it (Planning.cpp:186,214; Decision.cpp:203).  pp_set_* / pp_get_* do that
+ * with a host wait each, which drains the pipeline of overlapping ticks; the calls below never wait on the host:
+ *
+ *     pp_update_async(h, n, in_t, obs_t, NULL, n_obs);     // snapshot of tick t (pinned host memory, or device memory)
+ *     pp_plan_tick(h);
+ *     pp_fetch_async(h, plan_t, grid_t, &id_t);            // into pinned host memory (or device memory)
+ *     ... the same for t + 1, t + 2 ...                    // a few ticks deep
+ *     pp_wait_tick(h, id_t, NULL);                         // plan_t / grid_t are complete; in_t / obs_t may be reused
+ *
+ * Inputs are ring-buffered on the device (the searches of three ticks are in flight behind the newest front chain), PlanOut
+ * and GridOut too; uploads and downloads run on their own streams beside the kernels.  SceneState stays on the device.
+ * Host buffers should come from pp_host_alloc (or be pinned with pp_host_register): copies from / to pageable memory work
+ * but are staged by the runtime and wait on the host. */
+/* Replaces the per-tick inputs of the resident scenes for the NEXT pp_plan_tick (and the ticks after it, until the next
+ * update).  n_scenes must equal the resident count.  `in` NULL: SceneIn records carried over; obs_pool NULL: obstacles (and
+ * motion) carried over; mot_pool NULL with an obs_pool: static obstacles.  After pp_set_scenes the SceneIn slices are the
+ * caller's (lane and refpath pools stay resident); after pp_set_egos they are derived from the resident map as there.
+ * Nothing is refused asynchronously: a scene whose slices fall outside their pools (or whose road / lane is off the map) is
+ * POISONED - it runs that tick with empty lanes, refpath and obstacles - and pp_wait_tick reports how many there were.
+ * The source buffers must stay untouched until pp_wait_tick of the tick that adopts them (or pp_sync) has returned. */
+int  pp_update_async(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total);
+/* Downloads PlanOut and / or GridOut (either may be NULL) of the LAST enqueued tick, ordered after that tick's kernels only:
+ * PlanOut as soon as its Planning kernel has finished, GridOut after its scoring pass.  *tick_id (may be NULL) names the tick
+ * for pp_wait_tick.  The device copies are overwritten 12 ticks later, which those ticks order
+ * themselves after - the destination buffers are the caller's to rotate. */
+int  pp_fetch_async(pp_handle h, PlanOut* plan, GridOut* grid, long long* tick_id);
+/* Host wait for the downloads of one tick (at most 32 ticks back).  *n_poisoned (may be NULL): scenes of that tick's update
+ * that were poisoned; PP_ERR_ARG when there were any (the other scenes' results are valid), PP_OK otherwise. */
+int  pp_wait_tick(pp_handle h, long long tick_id, int* n_poisoned);
+long long pp_tick_id(pp_handle h);                   /* ticks enqueued on this handle so far = the id of the last one */
+/* Pinned host memory for the buffers above (hipHostMalloc / hipHostRegister). */
+void* pp_host_alloc(size_t bytes);
+void  pp_host_free(void* p);
+int   pp_host_register(void* p, size_t bytes);
+int   pp_host_unregister(void* p);
 
 /* ---- stand-alone operators on the path ------------------------------------------------------
  * CShare::SearchObstacle (11 call sites, e.g. Planning.cpp:168, Decision.cpp:811): query q

@@ -6,5 +6,5 @@
 N=${1:-3}
 for i in $(seq $N); do for v in prev cur; do
   if [ $v = prev ]; then export DMPP_LIB=$PWD/decision-making-and-path-planning_amd/libdmpp_prev.so; else unset DMPP_LIB; fi
-  python bench.py --no-cpu-baseline --latency-ticks 0 ${@:2} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['kernel_ms_avg']; print('$v', round(d['value']), ' '.join('%s=%.3f' % (a.replace('k_',''), b) for a, b in k.items()))"
+  python bench.py --no-cpu-baseline --latency-ticks 0 --no-extra-legs ${@:2} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['kernel_ms_avg']; print('$v', round(d['value']), ' '.join('%s=%.3f' % (a.replace('k_',''), b) for a, b in k.items()))"
 done; done

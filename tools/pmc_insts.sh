@@ -5,7 +5,7 @@ set -e
 TAG=${1:-x}
 export TMPDIR=/tmp
 R=$PWD
-ARGS="--no-cpu-baseline --latency-ticks 0 ${@:2}"
+ARGS="--no-cpu-baseline --latency-ticks 0 --no-extra-legs ${@:2}"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $R/gpurun_out/pmc_${TAG} -- python3 bench.py --steps 3 --warmup 1 $ARGS > gpurun_out/pmc_${TAG}.log 2>&1
 python3 - <<PY
 import csv, glob, collections

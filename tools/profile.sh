@@ -8,7 +8,7 @@ set -e
 TAG=${1:-r1}
 export TMPDIR=/tmp
 R=$PWD
-ARGS="--no-cpu-baseline --latency-ticks 0 ${@:2}"
+ARGS="--no-cpu-baseline --latency-ticks 0 --no-extra-legs ${@:2}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats -- python3 bench.py --steps 50 --warmup 5 $ARGS > gpurun_out/prof_${TAG}_stats.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_fetch -- python3 bench.py --steps 3 --warmup 1 $ARGS > gpurun_out/prof_${TAG}_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_write -- python3 bench.py --steps 3 --warmup 1 $ARGS > gpurun_out/prof_${TAG}_write.log 2>&1

@@ -4,7 +4,7 @@
 TAG=${1:-x}
 export TMPDIR=/tmp
 R=$PWD
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_${TAG} -- python3 bench.py --steps 12 --warmup 4 --no-cpu-baseline --latency-ticks 0 ${@:2} > gpurun_out/tl_${TAG}.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_${TAG} -- python3 bench.py --steps 12 --warmup 4 --no-cpu-baseline --latency-ticks 0 --no-extra-legs ${@:2} > gpurun_out/tl_${TAG}.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$R/gpurun_out/tl_${TAG}/**/*kernel_trace.csv", recursive=True)[0]

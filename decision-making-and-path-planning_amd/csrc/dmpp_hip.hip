@@ -109,6 +109,7 @@ struct pp_planner {
     hipEvent_t ev_raster = nullptr;
     bool score_recorded[kObs] = {}, search_recorded[kBuf] = {}, front_recorded = false, front_unjoined = false;
     int parity = 0;              // buffers of the last tick
+    bool last_piped = false;     // the last tick ran as three chains on several streams (else it ended on the handle's stream)
     int obs_set = 0;             // obstacle snapshot of the last tick (d_obs_now[obs_set])
     bool score_own_stream = false;   // env DMPP_SCORE_STREAM=1 (measurement knob): k_score on one stream of its own
     int n_cus = 256;
@@ -836,7 +837,7 @@ int pp_plan_tick(pp_handle h)
         if (piped) HIP_TRY(hipEventRecord(h->ev_score[po], ss));
         if (!piped && sr != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));   // one-stream mode: the tick is complete on the handle's stream
     }
-    h->parity = p; h->obs_set = po; h->gout_set = gs;
+    h->parity = p; h->obs_set = po; h->gout_set = gs; h->last_piped = piped;
     h->tick_seq++;
     if (h->streaming) {          // what a later update of this tick's input set, and a download of its results, wait for
         TickRec rec = { h->tick_seq, h->in_cur, get_sync_event(h), c.grid_stage ? get_sync_event(h) : nullptr };
@@ -1146,6 +1147,29 @@ int pp_wait_tick(pp_handle h, long long tick_id, int* n_poisoned)
     return PP_OK;
 }
 
+int pp_tick_io(pp_handle h, PpSceneIo* io)
+{
+    if (!h || !io) return fail(PP_ERR_ARG, "null argument");
+    if (h->n_scenes != 1) return fail(PP_ERR_STATE, "pp_tick_io moves ONE resident scene (pp_set_scenes with n_scenes = 1 comes first: its lane pool stays)");
+    if ((io->want & PP_IO_WANT_GRID) && !h->cfg.grid_stage) return fail(PP_ERR_STATE, "PP_IO_WANT_GRID: the handle's configuration has the grid stage off");
+    HIP_TRY(hipSetDevice(h->device));
+    const int max_obs = std::min(PP_IO_MAX_OBS, h->caps.max_obs_total), max_ref = std::min(DMPP_MAX_REFPATH, h->caps.max_ref_pts_total);
+    h->in_staged = -1;
+    hipLaunchKernelGGL(dmpp::k_io_in, dim3(1), dim3(dmpp::kBlock), 0, h->stream, io, max_obs, max_ref, h->n_lane_pts, h->d_in, h->d_state, h->d_obs, h->d_ref);
+    HIP_TRY(hipGetLastError());
+    h->n_obs_total = std::min(std::max((int)io->n_obs, 0), max_obs); h->have_motion = false;
+    h->n_ref_pts = std::max(h->n_ref_pts, max_ref);
+    note_current_set(h);
+    { int r = pp_plan_tick(h); if (r) return r; }
+    if (h->last_piped) { int r = join_all(h); if (r) return r; }      // (a one-scene tick ends on the handle's stream, as a rule: nothing to join)
+    hipLaunchKernelGGL(dmpp::k_io_out, dim3(1), dim3(dmpp::kBlock), 0, h->stream, io, (int)io->want, h->d_plan, h->d_state,
+                       h->cfg.grid_stage ? h->d_gout[h->gout_set] : nullptr, h->d_dec_ref);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (reinterpret_cast<volatile int32_t*>(&io->status)[0]) return fail(PP_ERR_ARG, "pp_tick_io: a lane slice of io->in lies outside the resident lane pool (the scene ran with empty lanes)");
+    return PP_OK;
+}
+
 void* pp_host_alloc(size_t bytes)
 {
     void* p = nullptr;
@@ -1423,7 +1447,7 @@ size_t pp_sizeof(int which)
     case 6: return sizeof(ObPoint); case 7: return sizeof(ObMotion); case 8: return sizeof(Path_Obs);
     case 9: return sizeof(LocationOut); case 10: return sizeof(DecisionOutPod); case 11: return sizeof(LaneView);
     case 12: return sizeof(PlanningOut); case 13: return sizeof(PlanningStatus); case 14: return sizeof(AimPoint);
-    case 15: return sizeof(MapLane); case 16: return sizeof(MapJunction); case 17: return sizeof(MapDesc);
+    case 15: return sizeof(MapLane); case 16: return sizeof(MapJunction); case 17: return sizeof(MapDesc); case 18: return sizeof(PpSceneIo);
     default: return 0;
     }
 }

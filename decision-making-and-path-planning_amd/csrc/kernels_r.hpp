@@ -253,6 +253,48 @@ k_sanitise_scenes(int n_scenes, SceneIn* __restrict__ in, int n_obs_total, int n
     }
 }
 
+// ---- pp_tick_io: the per-call inputs / outputs of ONE scene between a pinned host block and the device buffers ----
+// One workgroup; every thread moves 8-byte words (all the records are 8-byte aligned and sized).  The block lives in host
+// memory: the loads / stores below cross PCIe, all of them in flight together (no dependent round trips except the counts).
+__device__ inline void copy_words(void* __restrict__ dst, const void* __restrict__ src, size_t bytes)
+{
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
+    for (size_t i = threadIdx.x; i < bytes / 8; i += kBlock) d[i] = s[i];
+}
+__global__ void __launch_bounds__(kBlock)
+k_io_in(PpSceneIo* __restrict__ io, int max_obs, int max_ref, int n_lane_pts, SceneIn* __restrict__ in, SceneState* __restrict__ state,
+        ObPoint* __restrict__ obs, GlobalPoint2D* __restrict__ ref)
+{
+    const int n_obs = min(max(io->n_obs, 0), max_obs), n_ref = min(max(io->n_ref, 0), max_ref);
+    copy_words(in, &io->in, sizeof(SceneIn));
+    copy_words(state, &io->state, sizeof(SceneState));
+    copy_words(obs, io->obs, (size_t)n_obs * sizeof(ObPoint));
+    copy_words(ref, io->ref, (size_t)n_ref * sizeof(GlobalPoint2D));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        SceneIn& si = in[0];
+        si.obs_off = 0; si.obs_n = n_obs; si.ref_off = 0; si.ref_n = n_ref;
+        auto inside = [](int off, int n, int pool) { return n == 0 || (n > 0 && off >= 0 && (long long)off + n <= (long long)pool); };
+        const bool ok = inside(si.lanes.cur_off, si.lanes.cur_n, n_lane_pts) && inside(si.lanes.left_off, si.lanes.left_n, n_lane_pts) &&
+                        inside(si.lanes.right_off, si.lanes.right_n, n_lane_pts);
+        if (!ok) { si.lanes.cur_n = 0; si.lanes.left_n = 0; si.lanes.right_n = 0; si.lanes.cur_off = 0; si.lanes.left_off = 0; si.lanes.right_off = 0; }
+        io->status = ok ? 0 : 1;
+    }
+}
+__global__ void __launch_bounds__(kBlock)
+k_io_out(PpSceneIo* __restrict__ io, int want, const PlanOut* __restrict__ plan, const SceneState* __restrict__ state,
+         const GridOut* __restrict__ gout, const GlobalPoint2D* __restrict__ dec_ref)
+{
+    copy_words(&io->plan, plan, sizeof(PlanOut));
+    copy_words(&io->state, state, sizeof(SceneState));
+    if ((want & PP_IO_WANT_GRID) && gout) copy_words(&io->grid, gout, sizeof(GridOut));
+    if (want & PP_IO_WANT_REFPATH) {
+        const int n = min(max(plan[0].dec.refpath_n, 0), DMPP_MAX_REFPATH);
+        copy_words(io->dec_ref, dec_ref, (size_t)n * sizeof(GlobalPoint2D));
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Lane-change rule tree of CDecision::BehaviorDecision, Decision.cpp:1017-1772, run by one thread per scene
 // on the corridor distances k_decision has just produced.  `rem` holds the remaining-length tests (see

@@ -10,7 +10,6 @@ public:
     static CDecision& Instance();                 // Decision.cpp:36-40
     BYTE startCDecisionThread();                  // Decision.cpp:42-51: no thread; returns 1
 
-    void SetMap(const LaneMap& map) { m_map = map; }
     // junction_polyline: decision_InterMapData[...] for pos 1/2 (Decision.cpp:348); stub_attribute: Decision.cpp:385
     DecisionOut decide(const LocationOut& location, const vector<ObPoint>& obstacles,
                         const vector<GlobalPoint2D>& junction_polyline = {}, int stub_attribute = 0,
@@ -20,6 +19,5 @@ public:
 private:
     CDecision();
     ~CDecision() {}
-    LaneMap m_map;
     SceneState m_state;             // z_behavior, light, obstacle counters ... (Decision.h:27-44, Decision.cpp:915-917)
 };

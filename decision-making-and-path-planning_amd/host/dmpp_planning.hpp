@@ -45,7 +45,7 @@ public:
     double CalculateRadius();
 
     // ---- what replaces the blackboard (Planning.cpp:95-112) and the while(true) body ----
-    void SetMap(const LaneMap& map) { m_map = map; }
+    // (SetMap: CShare)
     // Frame of the grid stage (the search the reference only reserves behaviour code 6 "A*" for, Decision.h:36): world
     // position of the corner of cell (0,0) and the goal.  Without it plan(..., grid) searches from the ego to itself.
     void SetGridFrame(GlobalPoint2D origin, GlobalPoint2D goal) { m_origin = origin; m_goal = goal; m_frame = true; }
@@ -63,7 +63,6 @@ private:
     void tick(const DecisionOut& dec, const LocationOut& loc, const vector<ObPoint>& obs, SceneState& st,
               PlanOut& out, GridOut* grid, bool decision_stage);
     friend class CDecision;
-    LaneMap m_map;
     GlobalPoint2D m_origin{0, 0}, m_goal{0, 0}; bool m_frame = false;
     SceneState m_state;             // last_Bpoints, count, aim points ... (Planning.cpp:6,216-223)
     FLOAT faraim_dis = 0, nearaim_dis = 0;       // Planning.h:20-21

@@ -5,6 +5,7 @@
 // GPU through libdmpp.so — there is no host implementation of the arithmetic.
 #pragma once
 #include <vector>
+#include <mutex>
 #include "../../include/dmpp_planner.h"
 
 using std::vector;
@@ -46,13 +47,21 @@ struct LaneMap {
 // Raised into a flag instead of AfxMessageBox (Decision.cpp:514): the reference's methods return void
 struct DmppStatus { int code = 0; const char* text = ""; };
 
+// Threads.  The reference runs CDecision and CPlanning on a thread each (Decision.cpp:45, Planning.cpp:27), every object used
+// by its own thread only.  Here every object owns its GPU context - a pp_handle with its resident lane map and one pinned
+// PpSceneIo block - behind its own mutex: decide() and plan() may run concurrently on two threads, and two threads sharing
+// ONE object are serialised call by call.  The last status is per thread.  Config() is process-wide and read when a context
+// is (re)created and on every tick: set it before the threads start (the reference's macros are compile-time constants).
 class CShare {
 public:
-    // one GPU context per process for the single-scene class surface (device: env DMPP_DEVICE, default 0)
+    CShare();
+    virtual ~CShare();
+    CShare(const CShare&) = delete;
+    CShare& operator=(const CShare&) = delete;
+    // the planning singleton's context (created on first use); device: env DMPP_DEVICE, default 0
     static pp_handle Device();
-    static void Recreate();          // drops the context; the next Device() makes one for the current Config() (a larger grid)
     static PlannerConfig& Config();
-    static DmppStatus& LastStatus();
+    static DmppStatus& LastStatus();                                                                 // of the calling thread
 
     void   BezierPlanning(GlobalPoint3D start, GlobalPoint3D end, GlobalPoint2D out[], int n);       // Planning.cpp:606,863
     void   MeanPoints(GlobalPoint2D in[], int n_in, GlobalPoint2D out[], int n_out);                 // Planning.cpp:872
@@ -64,6 +73,25 @@ public:
     GPSPoint2D GlobalToWGS84(GlobalPoint2D p);                                                       // Planning.cpp:209
     int    NearestId(GlobalPoint2D p, vector<GlobalPoint2D> path);                                   // Decision.cpp:1889
     double LatDis(GlobalPoint2D p, GlobalPoint2D a, GlobalPoint2D b);                                // Decision.cpp:1895
+    void   SetMap(const LaneMap& map);             // planning_MapData / decision_MapData of this object: uploaded once, resident
 protected:
     static void note(int rc);
+    // this object's context; the methods below expect m_mu to be held
+    pp_handle handle(bool decision_stage, bool grid_stage);    // (re)creates the context / applies the stage switches when they differ
+    int upload_map(pp_handle h);                               // the LaneMap as the handle's ONE resident scene
+    // one tick of this object's scene through its PpSceneIo block (one host wait); state in / out, PlanOut (+ GridOut, refpath) out
+    int tick_io(bool decision_stage, const LocationOut& loc, const DecisionOutPod& dec, const vector<GlobalPoint2D>& ref,
+                const vector<ObPoint>& obs, int stub_attribute, double period_last_ms, const GlobalPoint2D* origin, const GlobalPoint2D* goal,
+                SceneState& st, PlanOut& out, GridOut* grid, vector<GlobalPoint2D>* refpath_out);
+    pp_handle op_handle();                                     // this object's context for a stand-alone operator (created when absent)
+    std::recursive_mutex m_mu;
+    LaneMap m_map;
+    bool m_grid_capable = false;                               // the context is created with the buffers of the grid stage (CPlanning)
+    bool m_decision_object = false;                            // the object ticks with the decision stage on (CDecision)
+private:
+    pp_handle m_h = nullptr;
+    PpSceneIo* m_io = nullptr;
+    PlannerConfig m_applied{}; bool m_have_applied = false;
+    bool m_map_dirty = true;
+    SceneIn m_in_template{};                     // lane slices of the resident map
 };

@@ -164,6 +164,28 @@ void  pp_host_free(void* p);
 int   pp_host_register(void* p, size_t bytes);
 int   pp_host_unregister(void* p);
 
+/* ---- one scene, one call, one host wait: the latency path of the class surface ------------------------------------------
+ * CPlanning::plan(...) / CDecision::decide(...) take everything by value on every call (Planning.h:57-75) and own the
+ * cross-tick state as members.  A PpSceneIo block (pinned host memory: pp_host_alloc(sizeof(PpSceneIo))) carries exactly that
+ * - location + decision, obstacle list, refpath / junction polyline, state in; PlanOut, state, GridOut, published refpath
+ * out - and pp_tick_io moves it with two small kernels that read / write the block over PCIe on the handle's stream, around
+ * one pp_plan_tick: no copy command, one host wait.  The handle must hold ONE resident scene (pp_set_scenes: its lane pool
+ * stays; io->in.lanes must lie inside it).  io->in.obs_off / obs_n / ref_off / ref_n are set from n_obs / n_ref. */
+#define PP_IO_MAX_OBS       1024
+#define PP_IO_WANT_GRID     1     /* io->grid is filled (the tick must run the grid stage) */
+#define PP_IO_WANT_REFPATH  2     /* io->dec_ref[0 .. plan.dec.refpath_n) is filled (decision stage) */
+typedef struct PpSceneIo {
+    SceneIn       in;
+    SceneState    state;                      /* in / out */
+    int32_t       n_obs, n_ref, want, status; /* status out: 0 ok, 1 a lane slice outside the resident pool (scene ran with empty lanes) */
+    ObPoint       obs[PP_IO_MAX_OBS];
+    GlobalPoint2D ref[DMPP_MAX_REFPATH];
+    PlanOut       plan;                       /* out */
+    GridOut       grid;                       /* out (PP_IO_WANT_GRID) */
+    GlobalPoint2D dec_ref[DMPP_MAX_REFPATH];  /* out (PP_IO_WANT_REFPATH) */
+} PpSceneIo;
+int  pp_tick_io(pp_handle h, PpSceneIo* io);
+
 /* ---- stand-alone operators on the path ------------------------------------------------------
  * CShare::SearchObstacle (11 call sites, e.g. Planning.cpp:168, Decision.cpp:811): query q
  * uses path points [path_off[q], path_off[q+1]) and obstacles [obs_off[q], obs_off[q+1]). */
@@ -204,7 +226,8 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes);
 void* pp_stream(pp_handle h);       /* hipStream_t; ordered after the ticks only after pp_join / pp_sync (see pp_plan_tick) */
 /* sizeof of an ABI struct, for bindings to check their mirror: 0 PlannerConfig, 1 PlannerCaps,
  * 2 SceneIn, 3 SceneState, 4 PlanOut, 5 GridOut, 6 ObPoint, 7 ObMotion, 8 Path_Obs, 9 LocationOut,
- * 10 DecisionOutPod, 11 LaneView, 12 PlanningOut, 13 PlanningStatus, 14 AimPoint */
+ * 10 DecisionOutPod, 11 LaneView, 12 PlanningOut, 13 PlanningStatus, 14 AimPoint, 15 MapLane, 16 MapJunction,
+ * 17 MapDesc, 18 PpSceneIo */
 size_t pp_sizeof(int which);
 /* The search keeps a scene's obstacle bitmaps sparse in LDS; a launch gives every scene `lds_budget_words` words per view
  * (sized from what the densest scene of an earlier tick needed) and a scene that needs more is searched on dense bitmaps

@@ -1170,6 +1170,15 @@ int pp_tick_io(pp_handle h, PpSceneIo* io)
     return PP_OK;
 }
 
+#ifdef DMPP_DEBUG_SEARCH
+int pp_debug_score_counters(int* out8, int reset)          // debug build only (tools/dbg_score.py)
+{
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(dmpp::g_dbg_score), 8 * sizeof(int)));
+    if (reset) { int z[8] = { 0 }; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dmpp::g_dbg_score), z, sizeof(z))); }
+    return PP_OK;
+}
+#endif
+
 void* pp_host_alloc(size_t bytes)
 {
     void* p = nullptr;

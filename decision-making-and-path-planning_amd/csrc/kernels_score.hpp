@@ -15,6 +15,14 @@ template <int NW> constexpr int kTailWaves = NW <= 4 ? NW : 1;
 static_assert(DMPP_PATH_POINTS - 192 == 8 && kTailFirst == 190 && kTailRounds * 8 <= DMPP_WAVE, "packed fourth pass: lane 8 c + j = point 192 + j of candidate c");
 static_assert(DMPP_PATH_POINTS <= kBoxWaves * DMPP_WAVE && DMPP_MAX_LATTICE <= 32, "score_body: lane layouts");
 constexpr int kMaxRelObs = 128;      // culled obstacle list kept in LDS; a scene with more candidates near its paths reads the whole list from HBM
+// Many obstacles near the candidates (256-obstacle scenes keep ~10 - 30 after the cull): a coarse bucket grid over the box of
+// the candidates, each culled obstacle entered into every bucket its cutoff disc can touch, so that a point only looks at the
+// list of ITS bucket.  The clearance is a minimum over the obstacles within their cutoff of the point - every one of them is in
+// the point's bucket - so the result is the same number (a minimum does not depend on the order or on extra far members).
+constexpr int kBucketN = 12, kBucketCap = 12, kBucketMinObs = 8;
+#ifdef DMPP_DEBUG_SEARCH
+__device__ int g_dbg_score[8];       // debug build: scenes scored, sum of n_rel, bucketed, bucket overflow, not culled, max n_rel
+#endif
 template <int NW>
 struct ScoreShared {
     GlobalPoint2D cand[NW][DMPP_PATH_POINTS];
@@ -29,6 +37,8 @@ struct ScoreShared {
     int box[4][4];                           // per wave: min / max cell column and row of the grid-path prefix
     GlobalPoint2D tail[kTailWaves<NW>][kTailRounds][DMPP_PATH_POINTS - kTailFirst];   // points 190 .. 199 of a wave's candidates (packed fourth pass)
     int best, n_rel;
+    int bcnt[kBucketN * kBucketN];                             // bucket fill counts (beyond kBucketCap: the bucket's points take the plain loop)
+    unsigned char bent[kBucketN * kBucketN][kBucketCap];       // indices into rx / ry / rr / rt2
 };
 
 __device__ __forceinline__ double wave_tree_sum(double acc)
@@ -153,6 +163,42 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
     __syncthreads();
     const bool culled = sh.n_rel <= kMaxRelObs;
     const int n_rel = culled ? sh.n_rel : m;
+    // ---- bucket grid (uniform decision per scene) ----
+    const double inv_bx = (X1 > X0) ? (double)kBucketN / (X1 - X0) : 0.0, inv_by = (Y1 > Y0) ? (double)kBucketN / (Y1 - Y0) : 0.0;
+    auto bucket_x = [&](double v) { return clampi((int)floor((v - X0) * inv_bx), 0, kBucketN - 1); };      // monotone in v: the obstacle's range and the
+    auto bucket_y = [&](double v) { return clampi((int)floor((v - Y0) * inv_by), 0, kBucketN - 1); };      // point's bucket come from the same expression
+    // culled scenes: entries index the LDS list; a scene with more than kMaxRelObs obstacles near its candidates (not culled) is
+    // bucketed straight from the snapshot in HBM (entries index it: <= 256 obstacles), so that its points read a few records
+    // instead of all of them.  A bucket that overflows sends only ITS points to the plain loop.
+    const bool bucketed = culled ? n_rel >= kBucketMinObs : m <= 256;
+    if (bucketed) {
+        for (int i = tid; i < kBucketN * kBucketN; i += kThreads) sh.bcnt[i] = 0;
+        __syncthreads();
+        for (int j = tid; j < n_rel; j += kThreads) {
+            double ox, oy, r;
+            if (culled) { ox = sh.rx[j]; oy = sh.ry[j]; r = sh.rr[j]; }
+            else { const ObPoint o = gobs[j]; ox = o.x; oy = o.y; r = (double)o.radius; }
+            // the cutoff, a hair wider: a point exactly at the cutoff (where the penalty is zero anyway) stays inside
+            const double thr = (r + half_w + c.d_safe) * (1.0 + 1e-9) + 1e-9;
+            if (!(ox >= X0 - thr && ox <= X1 + thr && oy >= Y0 - thr && oy <= Y1 + thr)) continue;       // (always true for the culled list)
+            const int bx0 = bucket_x(ox - thr), bx1 = bucket_x(ox + thr), by0 = bucket_y(oy - thr), by1 = bucket_y(oy + thr);
+            for (int by = by0; by <= by1; by++)
+                for (int bx = bx0; bx <= bx1; bx++) {
+                    const int b = by * kBucketN + bx;
+                    const int q = atomicAdd(&sh.bcnt[b], 1);
+                    if (q < kBucketCap) sh.bent[b][q] = (unsigned char)j;
+                }
+        }
+        __syncthreads();
+    }
+#ifdef DMPP_DEBUG_SEARCH
+    if (tid == 0) {
+        atomicAdd(&g_dbg_score[0], 1); atomicAdd(&g_dbg_score[1], sh.n_rel); atomicAdd(&g_dbg_score[2], bucketed ? 1 : 0);
+        { int ov = 0; if (bucketed) for (int i = 0; i < kBucketN * kBucketN; i++) ov += sh.bcnt[i] > kBucketCap; atomicAdd(&g_dbg_score[3], ov); }
+        atomicAdd(&g_dbg_score[4], culled ? 0 : 1);
+        atomicMax(&g_dbg_score[5], sh.n_rel);
+    }
+#endif
     GlobalPoint2D* cand = sh.cand[wave];
     // The Bezier parameter of a point, and with it the four basis weights, are the same for every lattice candidate: each
     // lane keeps those of its (<= 4) points (bezier_point's own expressions, so the points come out bit for bit the same).
@@ -167,7 +213,21 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
     // penalty and squared curvature of point i (= p) of the candidate whose points lie in cnd[]
     auto point_terms = [&](const GlobalPoint2D* cnd, int i, const GlobalPoint2D p, double& pen, double& kk2, bool& hit) {
         double clear = __builtin_inf();
-        if (__builtin_expect(culled, 1)) {
+        int nb = 0, b = 0;
+        if (bucketed) { b = bucket_y(p.y) * kBucketN + bucket_x(p.x); nb = sh.bcnt[b]; }
+        if (bucketed && nb <= kBucketCap) {
+            for (int e = 0; e < nb; e++) {
+                const int j = sh.bent[b][e];
+                double ox, oy, r, t2;
+                if (culled) { ox = sh.rx[j]; oy = sh.ry[j]; r = sh.rr[j]; t2 = sh.rt2[j]; }
+                else { ox = gobs[j].x; oy = gobs[j].y; r = (double)gobs[j].radius; const double thr = r + half_w + c.d_safe; t2 = thr * thr; }
+                const double dx = p.x - ox, dy = p.y - oy;
+                const double d2 = dx * dx + dy * dy;
+                if (d2 > t2) continue;
+                const double v = sqrt(d2) - r;
+                if (v < clear) clear = v;
+            }
+        } else if (__builtin_expect(culled, 1)) {
             for (int j = 0; j < n_rel; j++) {
                 const double dx = p.x - sh.rx[j], dy = p.y - sh.ry[j];
                 const double d2 = dx * dx + dy * dy;

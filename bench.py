@@ -48,6 +48,7 @@ def parse():
                     help="gloo: rehearsal of the N > 1 path with ranks sharing the GPUs of a smaller box (never a measured number)")
     ap.add_argument("--dump-gathered", default=None, help="rank 0 writes the gathered PlanOut / SceneState / GridOut of all ranks to this .npz (tests)")
     ap.add_argument("--no-verify-gather", action="store_true", help="skip the bit-for-bit check of the gathered shards on rank 0")
+    ap.add_argument("--bucket-cap", type=int, default=0, help="experiment: PlannerConfig.bucket_cap (0: the default); <= 512 means no open-list spill area and no retry kernel")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the streamed / one-shot / configs[3] / configs[4] legs behind the timed region")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the kernels of the timed region (no per-kernel times, no roofline)")
     return ap.parse_args()
@@ -231,6 +232,8 @@ def main():
     if args.dynamic:
         cfg["dynamic_obstacles"] = 1
         cfg["force_replan"] = 1
+    if args.bucket_cap:
+        cfg["bucket_cap"] = args.bucket_cap
     n = args.scenes
     n_obs = args.obstacles
     pl = dm.Planner(cfg, device=local_rank, max_scenes=n, max_obs_total=max(n * n_obs, 1))

@@ -90,6 +90,7 @@ struct pp_planner {
     uint8_t* d_grid = nullptr; uint16_t* d_pinfo[kBuf] = {}; uint32_t* d_closed[kBuf] = {};
     int32_t* d_order[kBuf] = {}; int32_t* d_path[kBuf] = {}; uint32_t* d_gbm[kBuf] = {};
     int32_t* d_perm[kBuf] = {}; int32_t* d_cost[kBuf] = {};
+    uint2* d_ospill[kBuf] = {}; int spill_cap = 0; int32_t* d_retry[kBuf] = {};     // open-list spill areas (bucket_cap0 entries per scene; none when bucket_cap0 <= the LDS list)
     // Long searches (many obstacles, large grids) overlap their tails: the searches of odd ticks run on a second stream, and
     // every buffer a search touches exists per tick parity
     hipStream_t stream_m[kBuf] = {}; int n_obs_total = 0; int overlap_override = -1;     // stream_m[0] is the handle's stream int overlap_override = -1;
@@ -321,12 +322,15 @@ int setup_grid_launch(pp_planner* h)
                                reinterpret_cast<const void*>(&dmpp::k_search<2, dmpp::kSearchSetupWaves>) };
         const void* fnw[3] = { reinterpret_cast<const void*>(&dmpp::k_search<0, dmpp::kSearchSetupWavesWide>), reinterpret_cast<const void*>(&dmpp::k_search<1, dmpp::kSearchSetupWavesWide>),
                                reinterpret_cast<const void*>(&dmpp::k_search<2, dmpp::kSearchSetupWavesWide>) };
+        const void* fnr[3] = { reinterpret_cast<const void*>(&dmpp::k_search_spill<0>), reinterpret_cast<const void*>(&dmpp::k_search_spill<1>),
+                               reinterpret_cast<const void*>(&dmpp::k_search_spill<2>) };
         const void* fne[3] = { reinterpret_cast<const void*>(&dmpp::k_export_grid<0>), reinterpret_cast<const void*>(&dmpp::k_export_grid<1>),
                                reinterpret_cast<const void*>(&dmpp::k_export_grid<2>) };
         const int dyn_max = std::max(h->search_meta_bytes + 8 * h->lds_budget_max, h->gbm_lds);
         if (dyn_max + (int)static_lds > 48 * 1024) {
             if (hipFuncSetAttribute(fns[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess ||
                 hipFuncSetAttribute(fnw[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess ||
+                hipFuncSetAttribute(fnr[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess ||
                 hipFuncSetAttribute(fne[h->search_kind], hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max) != hipSuccess) {
                 (void)hipGetLastError();
                 h->lds_budget_max = (int)std::min((size_t)h->lds_budget_max, (48u * 1024u - static_lds - (size_t)h->search_meta_bytes) / 8);
@@ -342,7 +346,8 @@ int setup_grid_launch(pp_planner* h)
             int r = dmalloc(&h->d_ovf[q], (size_t)h->caps.max_scenes); if (r) return r;
             HIP_TRY(hipMemsetAsync(h->d_ovf[q], 0, (size_t)h->caps.max_scenes * sizeof(int32_t), h->stream));
         }
-        if (!h->d_need[q]) { int r = dmalloc(&h->d_need[q], (size_t)1); if (r) return r; HIP_TRY(hipMemsetAsync(h->d_need[q], 0, sizeof(int32_t), h->stream)); }
+        if (!h->d_need[q]) { int r = dmalloc(&h->d_need[q], (size_t)2); if (r) return r; HIP_TRY(hipMemsetAsync(h->d_need[q], 0, 2 * sizeof(int32_t), h->stream)); }   // [0] LDS need of the search, [1] its retry count
+        if (!h->d_retry[q]) { int r = dmalloc(&h->d_retry[q], (size_t)h->caps.max_scenes); if (r) return r; }
     }
     if (!h->h_need) { HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_need), kBuf * sizeof(int32_t), hipHostMallocDefault)); for (int q = 0; q < kBuf; q++) h->h_need[q] = -1; }
     if (!h->d_gridbad) { int r = dmalloc(&h->d_gridbad, (size_t)2); if (r) return r; }
@@ -453,6 +458,10 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
         }
         for (int q = 0; q < kBuf; q++) if ((r = dmalloc(&h->d_path[q], ns * (size_t)cfg->max_path))) return bail(r);
         for (int q = 0; q < kBuf; q++) if (caps->order_cap > 0 && (r = dmalloc(&h->d_order[q], ns * (size_t)caps->order_cap))) return bail(r);
+        if (cfg->bucket_cap > DMPP_OPEN_CAP) {
+            h->spill_cap = cfg->bucket_cap;
+            for (int q = 0; q < kBuf; q++) if ((r = dmalloc(&h->d_ospill[q], ns * (size_t)h->spill_cap))) return bail(r);
+        }
         if ((r = setup_grid_launch(h))) return bail(r);
     }
     h->scratch_bytes = 4u << 20;
@@ -489,7 +498,7 @@ int pp_destroy(pp_handle h)
                      h->d_gridbad };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int q = 0; q < kBuf; q++)
-        for (void* b : { (void*)h->d_pinfo[q], (void*)h->d_closed[q], (void*)h->d_order[q], (void*)h->d_path[q],
+        for (void* b : { (void*)h->d_ospill[q], (void*)h->d_retry[q], (void*)h->d_pinfo[q], (void*)h->d_closed[q], (void*)h->d_order[q], (void*)h->d_path[q],
                          (void*)h->d_gbm[q], (void*)h->d_perm[q], (void*)h->d_cost[q], (void*)h->d_ovf[q], (void*)h->d_need[q] })
             if (b) (void)hipFree(b);
     for (int q = 0; q < kBuf; q++) if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]);
@@ -513,7 +522,9 @@ int pp_set_config(pp_handle h, const PlannerConfig* cfg)
     if (cfg->grid_stage) {
         if (!h->d_grid) return fail(PP_ERR_STATE, "handle was created without the grid stage");
         if ((size_t)cfg->grid_w * cfg->grid_h > h->grid_cells || cfg->max_path > h->max_path0)
-            return fail(PP_ERR_CAPACITY, "grid size / bucket_cap / max_path may not grow after pp_create");
+            return fail(PP_ERR_CAPACITY, "grid size / max_path may not grow after pp_create");
+        if (cfg->bucket_cap > DMPP_OPEN_CAP && cfg->bucket_cap > h->spill_cap)
+            return fail(PP_ERR_CAPACITY, "bucket_cap may not grow after pp_create beyond the larger of its value then and DMPP_OPEN_CAP (it sizes the open list's spill area)");
     }
     HIP_TRY(hipSetDevice(h->device));
     // a configuration change may move the next tick's kernels to other streams (grid stage on / off): finish what is queued
@@ -804,6 +815,7 @@ int pp_plan_tick(pp_handle h)
             const int budget = h->search_force_gbm ? 0 : h->lds_budget;
             const bool wide = n <= kScoreWideMaxScenes;       // a few scenes: sixteen waves set each scene up (the latency-bound tick)
             const size_t dyn = std::max((size_t)h->search_meta_bytes + 8 * (size_t)budget, (size_t)h->gbm_lds);
+            const bool use_spill = h->d_ospill[p] != nullptr && c.bucket_cap > DMPP_OPEN_CAP;     // scenes whose open list outgrows LDS are searched again, spilling
             {
                 Timed t(h, PP_K_SEARCH, sm);
                 switch (h->search_kind) {
@@ -811,10 +823,13 @@ int pp_plan_tick(pp_handle h)
                 case K:                                                                                                                        \
                     if (wide) hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWavesWide>), dim3(n), dim3(dmpp::kSearchSetupWavesWide * DMPP_WAVE), dyn, sm, c, n, h->caps.order_cap, budget, perm, \
                                            h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[gs], h->d_gbm[p], \
-                                           h->d_cost[p], h->d_ovf[p], h->d_need[p]);                                                         \
+                                           h->d_cost[p], h->d_ovf[p], h->d_need[p], h->d_ospill[p], h->spill_cap, h->d_retry[p], use_spill ? h->d_need[p] + 1 : nullptr); \
                     else hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWaves>), dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget, perm,  \
                                            h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[gs], h->d_gbm[p], \
-                                           h->d_cost[p], h->d_ovf[p], h->d_need[p]);                                                         \
+                                           h->d_cost[p], h->d_ovf[p], h->d_need[p], h->d_ospill[p], h->spill_cap, h->d_retry[p], use_spill ? h->d_need[p] + 1 : nullptr); \
+                    if (use_spill) hipLaunchKernelGGL((dmpp::k_search_spill<K>), dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget,                       \
+                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[gs], h->d_gbm[p],                              \
+                                           h->d_cost[p], h->d_ovf[p], h->d_need[p], h->d_ospill[p], h->spill_cap, h->d_retry[p], h->d_need[p] + 1);                           \
                     break;
                 DMPP_LAUNCH_SEARCH(0) DMPP_LAUNCH_SEARCH(1) DMPP_LAUNCH_SEARCH(2)
 #undef DMPP_LAUNCH_SEARCH

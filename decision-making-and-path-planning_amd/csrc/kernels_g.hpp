@@ -52,8 +52,9 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
     ScoreShared<NW>& sh = *reinterpret_cast<ScoreShared<NW>*>(smem_raw);
     const int scene = blockIdx.x;
     if (scene == 0 && threadIdx.x == 0 && need_dev) {
-        const int32_t v = *need_dev;
-        *need_dev = 0;
+        const int32_t v = need_dev[0];
+        need_dev[0] = 0;
+        need_dev[1] = 0;                       // the retry count of k_search / k_search_spill (same buffer set, three ticks on)
         if (need_host) *need_host = v;
     }
     if (scene >= n_scenes) return;

@@ -590,11 +590,128 @@ __device__ __forceinline__ int squeeze_open(LDS& L, int n_open, int lane)
     return w;
 }
 
+// ---- the open list beyond LDS --------------------------------------------------------------------------------------------
+// The specification allows bucket_cap live entries; LDS holds kOpenCap slots.  When a push does not fit, the entries that would
+// be popped LAST - largest f, and among equal f the oldest - go to the scene's spill area in HBM (spill_open keeps the
+// kOpenCap / 2 that pop first), appended in push order; when the minimum of the list in LDS reaches the smallest spilled f (or
+// the list cannot fill a batch of ties at that f), the newest spilled entries of that f come back IN FRONT of the list
+// (merge_open).  Invariant: among entries of equal f, every spilled one is older than every one in LDS, and the spill area
+// keeps push order - so "the latest push first" is decided inside LDS exactly as if nothing had been spilled.
+// A spill-area entry: x = the o_ent word, y = f / 2 | run << 16.  Both paths are rare (no generated scene spills).
+template <class LDS>
+__device__ __forceinline__ int spill_open(LDS& L, int n_open /* == live: squeezed */, int lane, uint2* __restrict__ ospill, int& sp_n, uint32_t& sp_min)
+{
+    constexpr int keep = kOpenCap / 2;
+    if (n_open <= keep) return n_open;
+    // pop priority key: f first, then the newer (higher slot) first; all keys distinct
+    uint32_t K[kOpenCap / DMPP_WAVE];
+#pragma unroll
+    for (int k = 0; k < kOpenCap / DMPP_WAVE; k++) {
+        const int slot = lane + DMPP_WAVE * k;
+        K[k] = slot < n_open ? (((uint32_t)L.o_f2[slot] << 16) | (0xFFFFu - (uint32_t)slot)) : 0xFFFFFFFFu;
+    }
+    uint32_t lo = 0u, hi = 0xFFFFFFFEu;                       // the keep-th smallest key
+    for (int it = 0; it < 32 && lo < hi; it++) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kOpenCap / DMPP_WAVE; k++) cnt += __popcll(wave_ballot(K[k] <= mid));
+        if (cnt >= keep) hi = mid; else lo = mid + 1u;
+    }
+    uint32_t mn = 0xFFFFu;
+    int base = sp_n;
+#pragma unroll
+    for (int k = 0; k < kOpenCap / DMPP_WAVE; k++) {
+        const int slot = lane + DMPP_WAVE * k;
+        const bool out = slot < n_open && K[k] > lo;
+        const unsigned long long bm = wave_ballot(out);
+        if (out) {
+            const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+            const uint32_t f2 = L.o_f2[slot];
+            ospill[base + r] = make_uint2(L.o_ent[slot], f2 | ((uint32_t)L.o_run[slot] << 16));
+            L.o_f2[slot] = 0xFFFFu;
+            mn = min(mn, f2);
+        }
+        base += __popcll(bm);
+    }
+    sp_n = base;
+    sp_min = min(sp_min, wave_min_u32(mn));
+    __threadfence();                                          // the wave reads its own spill area back later (merge_open)
+    wave_order();
+    return squeeze_open(L, n_open, lane);
+}
+
+// Brings the newest spilled entries of f / 2 == sp_min back, in front of the list.  Returns the new n_open (== live).
+template <class LDS>
+__device__ __forceinline__ int merge_open(LDS& L, int n_open, int lane, uint2* __restrict__ ospill, int& sp_n, uint32_t& sp_min)
+{
+    n_open = squeeze_open(L, n_open, lane);
+    if (kOpenCap - n_open < 2 * DMPP_WAVE) n_open = spill_open(L, n_open, lane, ospill, sp_n, sp_min);    // room for the batch's pushes and for what comes back
+    __threadfence();
+    const uint32_t X = sp_min;
+    int cntX = 0;
+    for (int q0 = 0; q0 < sp_n; q0 += DMPP_WAVE) {
+        const int i = q0 + lane;
+        const uint32_t f = i < sp_n ? (ospill[i].y & 0xFFFFu) : 0x10000u;
+        cntX += __popcll(wave_ballot(f == X));
+    }
+    const int room = kOpenCap - n_open - DMPP_WAVE;           // (>= 64: a step pushes at most 32)
+    const int take = min(cntX, room), skip = cntX - take;     // the oldest `skip` of them stay
+    // the list moves up by `take` slots (all reads, then all writes)
+    {
+        uint32_t f2[kOpenCap / DMPP_WAVE], ee[kOpenCap / DMPP_WAVE]; uint16_t rr[kOpenCap / DMPP_WAVE];
+#pragma unroll
+        for (int k = 0; k < kOpenCap / DMPP_WAVE; k++) {
+            const int slot = lane + DMPP_WAVE * k;
+            f2[k] = 0xFFFFu; ee[k] = 0; rr[k] = 0;
+            if (slot < n_open) { f2[k] = L.o_f2[slot]; ee[k] = L.o_ent[slot]; rr[k] = L.o_run[slot]; }
+        }
+        wave_order();
+#pragma unroll
+        for (int k = 0; k < kOpenCap / DMPP_WAVE; k++) {
+            const int slot = lane + DMPP_WAVE * k;
+            if (slot < n_open) { L.o_f2[slot + take] = (uint16_t)f2[k]; L.o_ent[slot + take] = ee[k]; L.o_run[slot + take] = rr[k]; }
+        }
+        wave_order();
+    }
+    // one pass over the spill area: the newest `take` entries of f == X go to slots 0 .. take - 1 (in push order), the others
+    // close up (stable), and the new minimum is taken on the way
+    int r = 0, w = 0; uint32_t nmin = 0xFFFFu;
+    for (int q0 = 0; q0 < sp_n; q0 += DMPP_WAVE) {
+        const int i = q0 + lane;
+        const bool valid = i < sp_n;
+        uint2 e = make_uint2(0u, 0xFFFFu);
+        if (valid) e = ospill[i];
+        const uint32_t f = e.y & 0xFFFFu;
+        const bool isX = valid && f == X;
+        const unsigned long long bx = wave_ballot(isX);
+        const int myr = r + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bx >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bx, 0u));
+        const bool tk = isX && myr >= skip;
+        if (tk) { const int dst = myr - skip; L.o_f2[dst] = (uint16_t)f; L.o_ent[dst] = e.x; L.o_run[dst] = (uint16_t)(e.y >> 16); }
+        const bool kp = valid && !tk;
+        const unsigned long long bk = wave_ballot(kp);
+        if (kp) {
+            ospill[w + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bk, 0u))] = e;
+            nmin = min(nmin, f);
+        }
+        r += __popcll(bx); w += __popcll(bk);
+    }
+    sp_n = w;
+    sp_min = wave_min_u32(nmin);
+    __threadfence();
+    wave_order();
+    return n_open + take;
+}
+
 // The search proper, one wave.  Vrow / Vcol: the two views; closed / pin: this scene's spill area in HBM.
-template <class V, class LDS>
+// SPILL = false: the open list lives in LDS only - the loop every generated scene runs; a scene that needs more live entries
+// than LDS holds ends with OVERFLOW there and, when the specification allows more (bucket_cap), is searched again by the
+// SPILL = true instance (k_search_spill), whose loop carries the spill state - kept out of the common loop: it cost 5 %
+// there in scalar-register spills.
+template <bool SPILL, class V, class LDS>
 __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L, const V& Vrow, const V& Vcol, int start, int goal, int order_cap,
                                         uint32_t* __restrict__ closed, uint16_t* __restrict__ pin, int32_t* __restrict__ order,
-                                        int32_t* __restrict__ path, int lane
+                                        int32_t* __restrict__ path, uint2* __restrict__ ospill, int lane
 #ifdef DMPP_DEBUG_SEARCH
                                         , long long* dbg_t, int* dbg_c
 #endif
@@ -609,7 +726,9 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
     constexpr int kClosedLog = LDS::kClosedLog, kClosedTab = LDS::kClosedTab, kClosedMax = LDS::kClosedMax;
     const int W = c.grid_w, H = c.grid_h, N = W * H;
     const int gx = goal % W, gy = goal / W;
-    const int cap = min(c.bucket_cap, kOpenCap);
+    // live entries allowed: the specification's bucket_cap; without a spill area (a handle made for bucket_cap <= kOpenCap) what LDS holds
+    const int cap = SPILL ? c.bucket_cap : min(c.bucket_cap, kOpenCap);
+    int sp_n = 0; uint32_t sp_min = 0xFFFFu;       // (SPILL) spilled entries (all live) and the smallest f / 2 among them
     SearchOut R; R.status = -1; R.n_exp = 0; R.n_push = 1; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
     int status = -1, n_exp = 0, n_push = 1, n_rounds = 0, path_cost = 0;
     uint64_t digest = 0;
@@ -643,7 +762,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
 #ifdef DMPP_DEBUG_SEARCH
         dbg_c[0]++;
 #endif
-        if (__builtin_expect(live == 0, 0)) { status = DMPP_G_NO_PATH; break; }
+        if (__builtin_expect((SPILL ? live + sp_n : live) == 0, 0)) { status = DMPP_G_NO_PATH; break; }
         // ---- pop: up to 4 entries of the smallest f, the latest pushes first ----
         // (1) squeeze the dead slots out when they outnumber the live ones: the scans below stay short
         if (__builtin_expect(n_open - live > 64 && n_open > 2 * live, 0)) n_open = squeeze_open(L, n_open, lane);
@@ -653,6 +772,8 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         const bool upper = n_open > 256;
         if (__builtin_expect(upper, 0)) { v4 = L.o_f2[lane + 256]; v5 = L.o_f2[lane + 320]; v6 = L.o_f2[lane + 384]; v7 = L.o_f2[lane + 448]; }
         const uint32_t fmin2 = wave_min_u32(min(min(min(v0, v1), min(v2, v3)), min(min(v4, v5), min(v6, v7))));
+        // spilled entries pop before the list's minimum: they come back first (the list in LDS may even be empty)
+        if constexpr (SPILL) if (__builtin_expect(sp_n > 0 && fmin2 > sp_min, 0)) { n_open = merge_open(L, n_open, lane, ospill, sp_n, sp_min); live = n_open; continue; }
         if (__builtin_expect(fmin2 == 0xFFFFu, 0)) { status = DMPP_G_INTERNAL; break; }
         const int f = (int)fmin2 << 1;
         // the (<= 4) slots taken, 16 bits each, first taken in the low bits (scalar: the tie masks are wave-uniform)
@@ -671,6 +792,8 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         DMPP_TAKE(v3, 192) DMPP_TAKE(v2, 128) DMPP_TAKE(v1, 64) DMPP_TAKE(v0, 0)
 #undef DMPP_TAKE
         static_assert(DMPP_JPS_BATCH == 4 && kOpenCap <= 65536, "four 16-bit slot numbers in one 64-bit scalar");
+        // ties at the smallest spilled f: the list's own (newer) ones go first, but a batch it cannot fill needs the spilled ones
+        if constexpr (SPILL) if (__builtin_expect(sp_n > 0 && fmin2 == sp_min && nt < DMPP_JPS_BATCH, 0)) { n_open = merge_open(L, n_open, lane, ospill, sp_n, sp_min); live = n_open; continue; }
         // every (node, s) lane reads its node's entry itself (a broadcast read): no cross-lane traffic afterwards
         const int i0 = (int)(sel & 0xFFFFu);
         const int myi = (int)((sel >> (16 * node)) & 0xFFFFu);
@@ -885,13 +1008,17 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
             // f/2 lives in 16 bits (0xFFFF = dead slot): a push at or beyond DMPP_F_LIMIT ends the search.  The oracle tests
             // each push in turn, the range before the capacity: the earlier of the two failing pushes decides the status.
             const unsigned rm = (unsigned)wave_ballot(push && fn >= DMPP_F_LIMIT);
-            if (__builtin_expect(rm || live + cnt > cap, 0)) {
+            const int live_all = SPILL ? live + sp_n : live;
+            if (__builtin_expect(rm || live_all + cnt > cap, 0)) {
                 const int k_range = rm ? __popc(pm & ((1u << (__ffs((int)rm) - 1)) - 1u)) : 0x7FFFFFFF;
-                const int k_cap = live + cnt > cap ? cap - live : 0x7FFFFFFF;
+                const int k_cap = live_all + cnt > cap ? cap - live_all : 0x7FFFFFFF;
                 status = k_range <= k_cap ? DMPP_G_COST_RANGE : DMPP_G_OVERFLOW;
-                break;
+                break;          // (SPILL = false and bucket_cap > kOpenCap: the caller sends the scene to the SPILL = true instance)
             }
-            if (__builtin_expect(n_open + cnt > kOpenCap, 0)) n_open = squeeze_open(L, n_open, lane);      // keeps the push order
+            if (__builtin_expect(n_open + cnt > kOpenCap, 0)) {
+                n_open = squeeze_open(L, n_open, lane);                                                    // keeps the push order
+                if constexpr (SPILL) { if (n_open + cnt > kOpenCap) n_open = spill_open(L, n_open, lane, ospill, sp_n, sp_min); live = n_open; }
+            }
             if (push) {
                 const int slot = n_open + __popc(pm & ((1u << lane) - 1u));
                 L.o_f2[slot] = (uint16_t)(fn >> 1);
@@ -1051,6 +1178,22 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
 #undef DBG_MARK
 }
 
+// the searching wave puts its LDS state back to "nothing expanded, the start node open" (before the second attempt)
+template <class LDS>
+__device__ __forceinline__ void reset_search_lds(LDS& L, int start, int goal, int W, int lane)
+{
+    for (int i = lane; i < LDS::kClosedTab; i += DMPP_WAVE) L.c_tab[i] = 0;
+    for (int i = lane; i < kOpenCap; i += DMPP_WAVE) L.o_f2[i] = 0xFFFFu;
+    wave_order();
+    if (lane == 0) {
+        const int sx = start % W, sy = start / W;
+        L.o_ent[0] = (uint32_t)sx | ((uint32_t)sy << 12) | (8u << 24);
+        L.o_f2[0] = (uint16_t)(hfun(sx, sy, goal % W, goal / W) >> 1);
+        L.o_run[0] = 0;
+    }
+    wave_order();
+}
+
 __device__ __forceinline__ void publish_search(GridOut& go, const SearchOut& R, int start, int goal)
 {
     go.order_digest = R.digest; go.status = R.status; go.n_expanded = R.n_exp; go.n_pushed = R.n_push; go.n_rounds = R.n_rounds;
@@ -1077,21 +1220,18 @@ __device__ __forceinline__ void publish_debug(int32_t* path, int max_path, const
 //   = 1) rasterises the dense form into gbitmaps (HBM) and is searched there - same loop, slower reads.  budget = 0 sends
 //   every scene that way (test knob).
 //   need_max: running maximum of the words a scene needed (the host sizes the next launches from it).
-template <int K, int SW>
-__global__ void __launch_bounds__(SW * DMPP_WAVE)
-k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
+//   retry_list / retry_cnt: scenes whose open list outgrew LDS (kStatusRetrySpill): searched again by k_search_spill.
+template <int K, int SW, bool SPILL>
+__device__ __forceinline__ void search_scene(const PlannerConfig& c, int scene, int order_cap, int budget, const SceneIn* __restrict__ in,
          const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
          int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out,
-         int32_t* __restrict__ overflow, int32_t* __restrict__ need_max)
+         int32_t* __restrict__ overflow, int32_t* __restrict__ need_max, uint2* __restrict__ ospill_all, int spill_cap,
+         int32_t* __restrict__ retry_list, int32_t* __restrict__ retry_cnt,
+         SearchLds<closed_log_of<K>()>& L, unsigned char* smem_raw)
 {
-    // static LDS: SearchLds; dynamic LDS: [line metas of both views | `budget` data words per view]
-    extern __shared__ __align__(16) unsigned char smem_raw[];
     using LdsT = SearchLds<closed_log_of<K>()>;
-    __shared__ LdsT L;
     constexpr unsigned kViewsAt = 0;
-    if ((int)blockIdx.x >= n_scenes) return;
     const long long t_begin = clock64();
-    const int scene = perm ? perm[blockIdx.x] : (int)blockIdx.x;      // heaviest scenes first (k_order) when they do not all fit at once
     const int tid = threadIdx.x, lane = tid & (DMPP_WAVE - 1), wv = tid >> 6;
     const int W = c.grid_w, H = c.grid_h, N = W * H, WW = W >> 5, HW = H >> 5;
     const SceneIn& si = in[scene];
@@ -1156,24 +1296,66 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t
     uint32_t* closed = gclosed + (size_t)scene * (N >> 5);
     uint16_t* pin = pinfo + (size_t)scene * N;
     int32_t* order = orders ? orders + (size_t)scene * order_cap : nullptr;
+    uint2* ospill = ospill_all ? ospill_all + (size_t)scene * spill_cap : nullptr;
 #ifdef DMPP_DEBUG_SEARCH
     long long dbg_t[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; int dbg_c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    if (!goal_blocked) R = dense ? search_core(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, lane, dbg_t, dbg_c)
-                                 : search_core(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, lane, dbg_t, dbg_c);
+    if (!goal_blocked) R = dense ? search_core<SPILL>(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, SPILL ? ospill : nullptr, lane, dbg_t, dbg_c)
+                                 : search_core<SPILL>(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, SPILL ? ospill : nullptr, lane, dbg_t, dbg_c);
     if (lane == 0) {
         publish_debug(path, c.max_path, dbg_t, dbg_c, t_setup, clock64() - t_begin);
         int32_t* d2 = path + c.max_path - 32;      // set-up phases: entry->clear, (unused x2), pass 1, offsets, zero, pass 2, tail
         d2[0] = (int)(tmark[0] - t_begin); for (int i = 1; i < 7; i++) d2[i] = (int)(tmark[i] - tmark[i - 1]); d2[7] = (int)(t_begin + t_setup - tmark[6]);
     }
 #else
-    if (!goal_blocked) R = dense ? search_core(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, lane)
-                                 : search_core(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, lane);
+    if (!goal_blocked) R = dense ? search_core<SPILL>(c, L, dr, dc, start, goal, order_cap, closed, pin, order, path, SPILL ? ospill : nullptr, lane)
+                                 : search_core<SPILL>(c, L, vr, vc, start, goal, order_cap, closed, pin, order, path, SPILL ? ospill : nullptr, lane);
 #endif
+    if (!SPILL && __builtin_expect(R.status == DMPP_G_OVERFLOW && retry_cnt != nullptr && c.bucket_cap > kOpenCap, 0)) {
+        // more live open-list entries than LDS holds, and the specification allows more: the scene goes on the list of
+        // k_search_spill, which follows on the stream (retry_cnt is null when the handle has no spill area)
+        if (lane == 0) retry_list[atomicAdd(retry_cnt, 1)] = scene;
+    }
     (void)t_setup;
     if (lane == 0) {
         cost_out[scene] = (int32_t)min((clock64() - t_begin) >> kOrderShift, (long long)(kOrderClasses - 1));   // launch-order key of the next tick (k_order)
         publish_search(gout[scene], R, start, goal);
     }
+}
+
+template <int K, int SW>
+__global__ void __launch_bounds__(SW * DMPP_WAVE)
+k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
+         const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
+         int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out,
+         int32_t* __restrict__ overflow, int32_t* __restrict__ need_max, uint2* __restrict__ ospill_all, int spill_cap,
+         int32_t* __restrict__ retry_list, int32_t* __restrict__ retry_cnt)
+{
+    // static LDS: SearchLds; dynamic LDS: [line metas of both views | `budget` data words per view]
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ SearchLds<closed_log_of<K>()> L;
+    if ((int)blockIdx.x >= n_scenes) return;
+    const int scene = perm ? perm[blockIdx.x] : (int)blockIdx.x;      // heaviest scenes first (k_order) when they do not all fit at once
+    search_scene<K, SW, false>(c, scene, order_cap, budget, in, obs_now, gclosed, pinfo, orders, paths, gout, gbitmaps, cost_out, overflow, need_max,
+                               ospill_all, spill_cap, retry_list, retry_cnt, L, smem_raw);
+}
+
+// The scenes the search kernel put on the retry list (their open list outgrew LDS), once more with the spill area.  Launched
+// behind every k_search of a handle that has a spill area, one workgroup per scene of the batch: all but the first
+// *retry_cnt of them leave at once (no generated scene ever comes here).
+template <int K>
+__global__ void __launch_bounds__(kSearchBlock)
+k_search_spill(PlannerConfig c, int n_scenes, int order_cap, int budget, const SceneIn* __restrict__ in,
+         const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
+         int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out,
+         int32_t* __restrict__ overflow, int32_t* __restrict__ need_max, uint2* __restrict__ ospill_all, int spill_cap,
+         const int32_t* __restrict__ retry_list, const int32_t* __restrict__ retry_cnt)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ SearchLds<closed_log_of<K>()> L;
+    if ((int)blockIdx.x >= min(*retry_cnt, n_scenes)) return;
+    const int scene = retry_list[blockIdx.x];
+    search_scene<K, kSearchSetupWaves, true>(c, scene, order_cap, budget, in, obs_now, gclosed, pinfo, orders, paths, gout, gbitmaps, cost_out, overflow,
+                                             need_max, ospill_all, spill_cap, nullptr, nullptr, L, smem_raw);
 }
 
 // pp_get_grid: one scene's occupancy grid as bytes, produced by the SAME footprint code the search uses (so the tests see

@@ -46,7 +46,7 @@ extern "C" void pp_default_config(PlannerConfig* c, int grid_w, int grid_h)
     c->grid_stage = 1;
     c->grid_w = grid_w; c->grid_h = grid_h;
     c->max_expansions = grid_w * grid_h;      // never binds unless lowered
-    c->bucket_cap = DMPP_OPEN_CAP;            // live open-list entries (the LDS-resident maximum)
+    c->bucket_cap = 4096;                     // live open-list entries (DMPP_OPEN_CAP of them in LDS, the rest in the spill area)
     c->max_path = 4 * (grid_w > grid_h ? grid_w : grid_h);
     c->n_lattice = 16; c->lookahead_cells = 120;
     c->dynamic_obstacles = 0; c->force_replan = 0;

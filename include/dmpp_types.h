@@ -184,7 +184,7 @@ typedef struct MapDesc {
 #define DMPP_G_FOUND      0
 #define DMPP_G_NO_PATH    1   /* open set exhausted */
 #define DMPP_G_LIMIT      2   /* max_expansions reached */
-#define DMPP_G_OVERFLOW   3   /* an open-set bucket exceeded bucket_cap */
+#define DMPP_G_OVERFLOW   3   /* more than bucket_cap live open-list entries */
 #define DMPP_G_GOAL_BLOCKED 4 /* goal cell occupied: no search run */
 #define DMPP_G_PATH_TRUNC 5   /* path longer than max_path cells */
 #define DMPP_G_INTERNAL   6   /* a loop bound of the device search was hit: never expected, reported instead of hanging */
@@ -193,7 +193,8 @@ typedef struct MapDesc {
 
 #define DMPP_JPS_BATCH 4       /* entries of the minimal f taken per step of the jump-point search */
 #define DMPP_DIAG_JUMP 8       /* cells a diagonal jump of the jump-point search looks ahead before it settles for a plain node */
-#define DMPP_OPEN_CAP 512      /* live entries of the jump-point search's open list (LDS resident; 496 is the most any generated scene needs) */
+#define DMPP_OPEN_CAP 512      /* open-list slots the device keeps in LDS (496 is the most any generated scene needs); beyond them the entries
+                                  that pop last live in a spill area in HBM, up to bucket_cap: a storage detail, not a limit of the specification */
 
 /* f = g + h of an open-list entry must stay below this (the device keeps f/2 in 16 bits, 0xFFFF = dead slot): ~13,000
  * straight cells of detour.  A push that would reach it ends the search with DMPP_G_COST_RANGE, checked - per push, in

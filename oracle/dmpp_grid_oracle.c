@@ -108,7 +108,8 @@ void orc_rasterise(const PlannerConfig* c, GlobalPoint2D origin, const ObPoint* 
  *             64-lane wave expands four nodes at once.
  *   stop    : goal closed (FOUND, at once: the rest of the step is skipped) | open set empty (NO_PATH)
  *             | n_expanded == max_expansions (LIMIT, at once)
- *             | more than open_cap = min(bucket_cap, DMPP_OPEN_CAP) live entries (OVERFLOW)
+ *             | more than bucket_cap live entries (OVERFLOW; the device keeps DMPP_OPEN_CAP of them in LDS and spills the
+ *               rest - the entries that would be popped last - to HBM: a storage detail, not a limit of the specification)
  *             | a successor with f >= DMPP_F_LIMIT (COST_RANGE; per push, tested before the capacity).
  *   path    : from the goal, each closed cell knows its arriving direction and run length; the cells
  *             of every run are written out, start..goal.
@@ -172,11 +173,16 @@ static int jump_diagonal(const JGrid* G, int x, int y, int s, int gx, int gy)
 
 typedef struct OEnt { int f, cell, dir, run; } OEnt;
 
+/* test aid: the largest number of live open-list entries of the last search on this thread (tests pick scenes that exceed what
+ * the device keeps in LDS) */
+static __thread int g_peak_open = 0;
+int orc_last_peak_open(void) { return g_peak_open; }
+
 void orc_grid_search(const PlannerConfig* c, const uint8_t* grid, int start_cell, int goal_cell,
                      GridOut* out, int32_t* order, int order_cap, int32_t* path, int path_cap)
 {
     const int W = c->grid_w, H = c->grid_h, N = W * H;
-    const int cap = c->bucket_cap < DMPP_OPEN_CAP ? c->bucket_cap : DMPP_OPEN_CAP;
+    const int cap = c->bucket_cap;
     out->start_cell = start_cell; out->goal_cell = goal_cell;
     out->status = DMPP_G_NO_PATH; out->n_expanded = 0; out->n_pushed = 0; out->n_rounds = 0;
     out->path_len = 0; out->path_cost = 0; out->order_digest = 0;
@@ -194,7 +200,9 @@ void orc_grid_search(const PlannerConfig* c, const uint8_t* grid, int start_cell
     open[n_open++] = (OEnt){ hfun(start_cell % W, start_cell / W, gx, gy), start_cell, 8, 0 };
     out->n_pushed = 1;
     int status = -1, fmax = -1;
+    g_peak_open = 1;
     while (status < 0) {
+        if (n_open > g_peak_open) g_peak_open = n_open;
         if (n_open == 0) { status = DMPP_G_NO_PATH; break; }
         int fmin = open[0].f;
         for (int i = 1; i < n_open; i++) if (open[i].f < fmin) fmin = open[i].f;

@@ -55,6 +55,7 @@ class Oracle:
         L.orc_plan_tick_batch.argtypes = [vp, ci] + [vp] * 10 + [ci]
         L.orc_plan_ticks_batch.argtypes = [vp, ci] + [vp] * 10 + [ci, ci]
         L.orc_last_refpath.argtypes = [vp, ci]
+        L.orc_last_peak_open.restype = ci
 
     # ---- scalar helpers ----
     def GetLatDis(self, cfg, cur, pt, nxt):
@@ -125,6 +126,10 @@ class Oracle:
         path = np.zeros(mp, np.int32)
         self.L.orc_grid_search(_p(cfg), _p(grid), start, goal, _p(out), _p(order) if order_cap else None, order_cap, _p(path), mp)
         return out, order[: min(order_cap, int(out["n_expanded"][0]))], path[: int(out["path_len"][0])]
+
+    def last_peak_open(self):
+        """Largest number of live open-list entries during the last grid_search / plan_tick_one on this thread."""
+        return self.L.orc_last_peak_open()
 
     def effective_obstacles(self, cfg, obs, mot, tick):
         out = np.zeros(len(obs), dm.ObPoint)

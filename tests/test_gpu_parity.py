@@ -715,6 +715,42 @@ def test_cost_range_serpentine_2048(dm, oracle, n_walls, want):
         assert (pl.get_path(0, int(go["path_len"])) == path_o).all()
 
 
+@pytest.mark.parametrize("grid,n_side,radius,min_peak", [(1024, 40, 0.05, 1500), (2048, 44, 0.2, 2000)])
+def test_open_list_spills_to_hbm(dm, oracle, grid, n_side, radius, min_peak):
+    """Thousands of live open-list entries (a field of small discs behind two walls: the search floods it): the device keeps
+    DMPP_OPEN_CAP slots in LDS and spills the entries that pop last to HBM, merging them back as the minimum rises.  Status,
+    expansion order, path and every counter must be the oracle's - and with bucket_cap below the peak both must overflow."""
+    from grid_scenes import pebble_field
+    cfg = dm.default_config(grid)
+    cfg["bucket_cap"] = 16384
+    cfg["max_path"] = 32768
+    sc = pebble_field(dm, cfg, n_side=n_side, radius=radius)
+    cap_order = 1 << 18
+    pl, res = _tick_both(dm, oracle, cfg, sc, n_ticks=1, order_cap=cap_order)
+    _assert_tick(res[0], "spilling open list")
+    st1 = sc["state"].copy()
+    _, go, _, order_o, path_o = oracle.plan_tick_one(cfg, sc, 0, st1, order_cap=cap_order)
+    peak = oracle.last_peak_open()
+    assert int(go["status"]) == 0 and peak > min_peak, (int(go["status"]), peak)
+    assert (pl.get_order(0, int(go["n_expanded"])) == order_o).all()
+    assert (pl.get_path(0, int(go["path_len"])) == path_o).all()
+    # the same scene with fewer entries allowed than it needs: OVERFLOW in both (only the status is specified)
+    cfg["bucket_cap"] = peak - 50
+    pl.set_config(cfg)
+    pl.set_state(sc["state"])
+    pl.tick(sync=True)
+    st2 = sc["state"].copy()
+    _, go2, _, _, _ = oracle.plan_tick_one(cfg, sc, 0, st2)
+    assert int(go2["status"]) == dm.G_OVERFLOW and int(pl.get_grid_out()["status"][0]) == dm.G_OVERFLOW
+    # a handle made for bucket_cap <= DMPP_OPEN_CAP has no spill area and refuses a larger cap later
+    small = dm.default_config(128)
+    small["bucket_cap"] = 512
+    p2 = dm.Planner(small, max_scenes=1)
+    small["bucket_cap"] = 4096
+    with pytest.raises(dm.PlannerError, match="bucket_cap"):
+        p2.set_config(small)
+
+
 def test_unsynced_ticks_then_grid_and_stage_switch(dm, oracle):
     """What a caller may do between ticks without a host sync (the three-stream tick, n >= 256): read the grid of the last
     tick (pp_get_grid expands the bitmaps the rasteriser wrote on another stream), then switch the grid stage off and on

@@ -6,8 +6,11 @@ import numpy as np, dmpp_amd as dm
 dm.load_library(os.path.join(os.path.dirname(dm.LIB_PATH), 'libdmpp_dbg.so'))   # make -C .../csrc debug
 cfg = dm.default_config(512)
 n=1024
-sc = dm.gen_scenes(cfg, 0, n, 64, 8)
-pl = dm.Planner(cfg, max_scenes=n, max_obs_total=n*64)
+N_OBS = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+DYN = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+cfg["dynamic_obstacles"] = DYN; cfg["force_replan"] = DYN
+sc = dm.gen_scenes(cfg, 0, n, N_OBS, 8)
+pl = dm.Planner(cfg, max_scenes=n, max_obs_total=n*N_OBS)
 pl.set_scenes(sc); pl.set_state(sc['state']); pl.tick(sync=True); pl.tick(sync=True)
 g = pl.get_grid_out()
 mp=int(cfg['max_path'][0])

@@ -1289,7 +1289,7 @@ __device__ __forceinline__ void search_scene(const PlannerConfig& c, int scene, 
     }
     __syncthreads();
     int32_t* path = paths + (size_t)scene * c.max_path;
-    if (wv != 0) return;                       // set-up done: the search is wave 0's
+    if (wv != 0) return;                       // set-up done: the search is wave 0's (k_search_spill: the others wait at its barrier for the workgroup's next scene)
     __builtin_amdgcn_s_setprio(1);             // a latency-bound wave: ahead of the set-up waves and of the kernels that run beside it
     const long long t_setup = clock64() - t_begin;
     SearchOut R; R.status = DMPP_G_GOAL_BLOCKED; R.n_exp = 0; R.n_push = 0; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
@@ -1340,8 +1340,8 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t
 }
 
 // The scenes the search kernel put on the retry list (their open list outgrew LDS), once more with the spill area.  Launched
-// behind every k_search of a handle that has a spill area, one workgroup per scene of the batch: all but the first
-// *retry_cnt of them leave at once (no generated scene ever comes here).
+// behind every k_search of a handle that has a spill area, with a handful of workgroups that take the list's scenes in turn
+// (no generated scene ever comes here: they find the list empty and leave).
 template <int K>
 __global__ void __launch_bounds__(kSearchBlock)
 k_search_spill(PlannerConfig c, int n_scenes, int order_cap, int budget, const SceneIn* __restrict__ in,
@@ -1352,10 +1352,13 @@ k_search_spill(PlannerConfig c, int n_scenes, int order_cap, int budget, const S
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ SearchLds<closed_log_of<K>()> L;
-    if ((int)blockIdx.x >= min(*retry_cnt, n_scenes)) return;
-    const int scene = retry_list[blockIdx.x];
-    search_scene<K, kSearchSetupWaves, true>(c, scene, order_cap, budget, in, obs_now, gclosed, pinfo, orders, paths, gout, gbitmaps, cost_out, overflow,
-                                             need_max, ospill_all, spill_cap, nullptr, nullptr, L, smem_raw);
+    const int cnt = min(*retry_cnt, n_scenes);
+    for (int i = (int)blockIdx.x; i < cnt; i += (int)gridDim.x) {      // (a handful of workgroups: nearly always there is nothing to do, and they must not queue for LDS behind the searches)
+        const int scene = retry_list[i];
+        search_scene<K, kSearchSetupWaves, true>(c, scene, order_cap, budget, in, obs_now, gclosed, pinfo, orders, paths, gout, gbitmaps, cost_out, overflow,
+                                                 need_max, ospill_all, spill_cap, nullptr, nullptr, L, smem_raw);
+        __syncthreads();                       // every wave is done with this scene's LDS
+    }
 }
 
 // pp_get_grid: one scene's occupancy grid as bytes, produced by the SAME footprint code the search uses (so the tests see

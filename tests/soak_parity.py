@@ -9,8 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import torch                                   # noqa: F401  (initialises the ROCm runtime the way bench.py does)
-torch.cuda.is_available()
+if os.environ.get("SOAK_TORCH"):               # the library on the HIP runtime bundled with torch (what a caller that imports torch first gets)
+    import torch                               # noqa: F401
+    torch.cuda.is_available()
 import dmpp_amd as dm
 import oracle_binding
 from parity_util import compare, move_ego
@@ -90,14 +91,48 @@ def main():
         if rng.integers(0, 3) == 0:
             sc["scene_in"]["period_last"] = float(rng.choice([100.0, 900.0, 1700.0]))
         one_shot = bool(rng.integers(0, 3) == 0)            # host buffers through pp_plan_tick_batch, state carried by the caller
+        streamed = seed0 >= 40 and not one_shot and bool(rng.integers(0, 3) == 0)   # seeds from 40 on: pp_update_async / pp_fetch_async, every tick compared
+        if seed0 >= 40 and rng.integers(0, 12) == 0 and gw == gh and grid in (256, 512, 1024):
+            # a field of small discs behind walls: thousands of live open-list entries (the spill area of the open list)
+            from grid_scenes import pebble_field
+            cfg["bucket_cap"] = int(rng.choice([700, 2000, 16384]))
+            cfg["max_path"] = 32768
+            sc = pebble_field(dm, cfg, n_side=int(rng.integers(8, grid // 24)), radius=float(rng.choice([0.05, 0.2, 0.6])),
+                              jitter=float(rng.choice([0.5, 2.0])), seed=int(rng.integers(0, 1 << 20)), walls=int(rng.integers(1, 4)))
+            n, n_obs, dynamic = 1, sc["n_obs"], 0
+            cfg["dynamic_obstacles"] = 0
+            sc["n_obs"] = n_obs
         pl = dm.Planner(cfg, device=0, max_scenes=n, max_obs_total=max(n * n_obs, 1))
         pl.set_state(sc["state"])
         st_o = sc["state"].copy()
         st_h = sc["state"].copy()
         bad = []
+        fetched = []
+        if streamed:
+            pl.set_scenes(sc)
         for t in range(n_ticks):
             if t and rng.integers(0, 2):
                 move_ego(sc, int(rng.integers(1, 9)), dlat=float(rng.choice([0.0, 0.2, -0.4])))
+            if streamed:
+                if n_obs:
+                    sc["obs_pool"]["x"] += rng.uniform(-0.2, 0.2, len(sc["obs_pool"]))
+                a, b = dm.pinned_copy(sc["scene_in"]), dm.pinned_copy(sc["obs_pool"])
+                mo = dm.pinned_copy(sc["mot_pool"])
+                pl.update_async(a, b, mo, n_obs_total=n * n_obs)
+                pl.tick()
+                pg, gg = dm.pinned_empty(n, dm.PlanOut), dm.pinned_empty(n, dm.GridOut)
+                tid = pl.fetch_async(pg, gg)
+                plan_o, gout_o, _ = orc.plan_tick_batch(cfg, sc, st_o, n_threads=threads, want_grid=True)
+                fetched.append((tid, pg, gg, plan_o, gout_o, a, b, mo))
+                if t == n_ticks - 1:
+                    for (tid, pg, gg, po_, go_, _, _, _) in fetched:
+                        pl.wait_tick(tid)
+                        bad += compare(pg, po_, "plan") + compare(gg["status"], go_["status"], "grid.status")
+                        keep = (go_["status"] != 3) & (go_["status"] != 7)
+                        bad += compare(gg[keep], go_[keep], "grid")
+                    pl.sync()
+                    bad += compare(pl.get_state(), st_o, "state")
+                continue
             if one_shot:
                 plan_g, gout_g = pl.plan_tick_batch(sc, st_h)
             else:
@@ -119,7 +154,7 @@ def main():
         pl.close()
         it += 1
         scenes_done += n * n_ticks
-        tag = f"it {it} grid {gw}x{gh} n {n} obs {n_obs} dyn {dynamic} first {first} jevery {jevery} ticks {n_ticks} sync {int(sync_each)} oneshot {int(one_shot)} " \
+        tag = f"it {it} grid {gw}x{gh} n {n} obs {n_obs} dyn {dynamic} first {first} jevery {jevery} ticks {n_ticks} sync {int(sync_each)} oneshot {int(one_shot)} streamed {int(streamed)} cap {int(cfg['bucket_cap'][0])} " \
               f"dec {int(cfg['decision_stage'][0])} lc {int(cfg['lanechg_stage'][0])} force {int(cfg['force_replan'][0])}"
         if bad:
             bad_total += 1

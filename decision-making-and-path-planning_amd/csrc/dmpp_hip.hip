@@ -827,7 +827,7 @@ int pp_plan_tick(pp_handle h)
                     else hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWaves>), dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget, perm,  \
                                            h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[gs], h->d_gbm[p], \
                                            h->d_cost[p], h->d_ovf[p], h->d_need[p], h->d_ospill[p], h->spill_cap, h->d_retry[p], use_spill ? h->d_need[p] + 1 : nullptr); \
-                    if (use_spill) hipLaunchKernelGGL((dmpp::k_search_spill<K>), dim3(std::min(n, 16)), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget,                       \
+                    if (use_spill) hipLaunchKernelGGL((dmpp::k_search_spill<K>), dim3(std::min(n, 2)), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget,                       \
                                            h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[gs], h->d_gbm[p],                              \
                                            h->d_cost[p], h->d_ovf[p], h->d_need[p], h->d_ospill[p], h->spill_cap, h->d_retry[p], h->d_need[p] + 1);                           \
                     break;

@@ -1340,8 +1340,11 @@ k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t
 }
 
 // The scenes the search kernel put on the retry list (their open list outgrew LDS), once more with the spill area.  Launched
-// behind every k_search of a handle that has a spill area, with a handful of workgroups that take the list's scenes in turn
-// (no generated scene ever comes here: they find the list empty and leave).
+// behind every k_search of a handle that has a spill area, with TWO workgroups that take the list's scenes in turn (no generated
+// scene ever comes here: they find the list empty and leave - but each has to wait for LDS behind the searching workgroups of
+// the neighbouring ticks first, which is why there are so few of them: one per scene cost 25 - 130 us per tick).
+// Measured and not kept: both instances of the search loop in one kernel (104 -> 132 VGPRs, twice the scalar spills in the
+// common loop: -5 %), and the second attempt as a call from the kernel's tail (scratch + 142 VGPRs: -10 %).
 template <int K>
 __global__ void __launch_bounds__(kSearchBlock)
 k_search_spill(PlannerConfig c, int n_scenes, int order_cap, int budget, const SceneIn* __restrict__ in,

@@ -157,8 +157,10 @@ def streamed_leg(dm, np, pl, sc, n, n_obs, steps, depth=6):
         snaps.append((dm.pinned_copy(work["scene_in"]), dm.pinned_copy(work["obs_pool"])))
     plans = [dm.pinned_empty(n, dm.PlanOut) for _ in range(depth)]
     grids = [dm.pinned_empty(n, dm.GridOut) for _ in range(depth)]
+    ress = [dm.pinned_empty(n, dm.PlanningOut) for _ in range(depth)]
+    shows = [dm.pinned_empty(n, dm.PlanningStatus) for _ in range(depth)]
 
-    def run(k_steps):
+    def run(k_steps, published_only):
         ids = []
         for t in range(k_steps):
             if len(ids) == depth:
@@ -166,18 +168,29 @@ def streamed_leg(dm, np, pl, sc, n, n_obs, steps, depth=6):
             a, b = snaps[t % len(snaps)]
             pl.update_async(a, b)
             pl.tick()
-            ids.append(pl.fetch_async(plans[t % depth], grids[t % depth]))
+            if published_only:
+                ids.append(pl.fetch_published_async(ress[t % depth], shows[t % depth], grids[t % depth]))
+            else:
+                ids.append(pl.fetch_async(plans[t % depth], grids[t % depth]))
         for i in ids:
             pl.wait_tick(i)
-    run(3 * depth)
-    pl.sync()
-    t0 = time.perf_counter()
-    run(steps)
-    pl.sync()
-    dt = time.perf_counter() - t0
+
+    def timed(published_only):
+        run(3 * depth, published_only)
+        pl.sync()
+        t0 = time.perf_counter()
+        run(steps, published_only)
+        pl.sync()
+        return time.perf_counter() - t0
+    dt = timed(False)
+    dt_pub = timed(True)
     up = n * dm.SceneIn.itemsize + n * n_obs * dm.ObPoint.itemsize
     down = n * (dm.PlanOut.itemsize + dm.GridOut.itemsize)
-    return {"ticks_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "ticks_in_flight": depth,
+    down_pub = n * (dm.PlanningOut.itemsize + dm.PlanningStatus.itemsize + dm.GridOut.itemsize)
+    return {"published_only": {"ticks_per_s": n * steps / dt_pub, "ms_per_step": dt_pub / steps * 1e3, "MB_down": down_pub / 1e6,
+                               "note": "pp_fetch_published_async: PlanningOut + PlanningStatus (what SetUdpSendCtrl / SetPlanningStatus receive, "
+                                       "Planning.cpp:186,214) + GridOut instead of the whole PlanOut + GridOut"},
+            "ticks_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "ticks_in_flight": depth,
             "MB_up": up / 1e6, "MB_down": down / 1e6, "PCIe_GBps_up": up * steps / dt / 1e9, "PCIe_GBps_down": down * steps / dt / 1e9,
             "note": "per tick: SceneIn + obstacle pool uploaded from pinned host memory, PlanOut + GridOut of every scene downloaded "
                     "into pinned host memory; no host wait except for the tick `ticks_in_flight` behind"}
@@ -400,6 +413,8 @@ def main():
                               "PlanOut + SceneState + GridOut downloaded, host waits between the stages (PCIe-inclusive; never the headline)"}
         if n == 1024 and n_obs == 64 and not args.dynamic and args.grid == 512:
             other = {}
+            pl.close()      # one handle at a time: the streams of a second handle share the process's few hardware queues with the first one's,
+                            # and its three searches then queue behind each other instead of overlapping (measured: 0.68 instead of 1.15 M ticks/s)
             for name, (g2, o2, dyn2, tag2) in (("configs[3]", (512, 256, 1, "c3")), ("configs[4]", (2048, 64, 0, "c4"))):
                 cfg2 = dm.default_config(g2)
                 if dyn2:

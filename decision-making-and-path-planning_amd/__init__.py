@@ -163,6 +163,7 @@ def load_library(path=None):
     lib.pp_stream.restype = vp
     lib.pp_update_async.argtypes = [vp, ci, vp, vp, vp, ci]
     lib.pp_fetch_async.argtypes = [vp, vp, vp, C.POINTER(C.c_longlong)]
+    lib.pp_fetch_published_async.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_longlong)]
     lib.pp_wait_tick.argtypes = [vp, C.c_longlong, C.POINTER(ci)]
     lib.pp_tick_id.argtypes = [vp]
     lib.pp_tick_id.restype = C.c_longlong
@@ -345,6 +346,12 @@ class Planner:
         """pp_fetch_async of the last enqueued tick into `plan` / `grid` (pinned arrays of self.n records). Returns the tick id."""
         t = C.c_longlong()
         _check(self.lib.pp_fetch_async(self.h, _ptr(plan), _ptr(grid), C.byref(t)))
+        return t.value
+
+    def fetch_published_async(self, result=None, show=None, grid=None):
+        """pp_fetch_published_async: PlanningOut / PlanningStatus arrays (what the reference publishes) and / or GridOut of the last tick."""
+        t = C.c_longlong()
+        _check(self.lib.pp_fetch_published_async(self.h, _ptr(result), _ptr(show), _ptr(grid), C.byref(t)))
         return t.value
 
     def wait_tick(self, tick_id, allow_poisoned=False):

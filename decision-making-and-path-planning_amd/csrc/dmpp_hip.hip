@@ -10,6 +10,7 @@
 // the host; the streamed calls never wait on the host (pp_wait_tick waits for one tick's downloads only).
 // Nothing here computes planning results on the host; without a GPU pp_create fails.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -66,6 +67,7 @@ struct TickRec { long long tick; int in_set; hipEvent_t ev_front, ev_tail; };
 struct PendingFetch {
     long long tick; int slot;
     PlanOut* plan_dst; const PlanOut* plan_src; int plan_set; bool plan_issued;
+    PlanningOut* res_dst; PlanningStatus* show_dst;      // pp_fetch_published_async: only what the reference publishes (strided copies out of PlanOut)
     GridOut* grid_dst; const GridOut* grid_src; int grid_set; bool grid_issued;
     hipEvent_t ev_front, ev_tail;      // own references: taken out of the tick's TickRec so that they are not recycled early
     size_t n;
@@ -202,12 +204,15 @@ void note_current_set(pp_planner* h)          // after a pp_set_* call changed w
 int pump_fetches(pp_planner* h, long long force_tick = -1, int force_plan_set = -1, int force_grid_set = -1)
 {
     for (PendingFetch& f : h->fetches) {
-        if (f.plan_dst && !f.plan_issued) {
+        if ((f.plan_dst || f.res_dst || f.show_dst) && !f.plan_issued) {
             const bool ready = hipEventQuery(f.ev_front) == hipSuccess;
             if (ready || f.tick == force_tick || f.plan_set == force_plan_set) {
                 (void)hipGetLastError();
                 if (!ready) HIP_TRY(hipStreamWaitEvent(h->stream_dp, f.ev_front, 0));
-                HIP_TRY(hipMemcpyAsync(f.plan_dst, f.plan_src, f.n * sizeof(PlanOut), hipMemcpyDefault, h->stream_dp));
+                if (f.plan_dst) HIP_TRY(hipMemcpyAsync(f.plan_dst, f.plan_src, f.n * sizeof(PlanOut), hipMemcpyDefault, h->stream_dp));
+                const char* base = reinterpret_cast<const char*>(f.plan_src);
+                if (f.res_dst) HIP_TRY(hipMemcpy2DAsync(f.res_dst, sizeof(PlanningOut), base + offsetof(PlanOut, result), sizeof(PlanOut), sizeof(PlanningOut), f.n, hipMemcpyDefault, h->stream_dp));
+                if (f.show_dst) HIP_TRY(hipMemcpy2DAsync(f.show_dst, sizeof(PlanningStatus), base + offsetof(PlanOut, show), sizeof(PlanOut), sizeof(PlanningStatus), f.n, hipMemcpyDefault, h->stream_dp));
                 HIP_TRY(hipEventRecord(h->ev_fetched_plan[f.plan_set], h->stream_dp)); h->fetched_plan_rec[f.plan_set] = true;
                 HIP_TRY(hipEventRecord(h->ev_done_p[f.slot], h->stream_dp));
                 f.plan_issued = true;
@@ -228,7 +233,8 @@ int pump_fetches(pp_planner* h, long long force_tick = -1, int force_plan_set = 
     }
     (void)hipGetLastError();                  // hipErrorNotReady is not an error here
     size_t k = 0;                             // completed requests leave from the front (prune_inflight looks at the first one left)
-    while (k < h->fetches.size() && (!h->fetches[k].plan_dst || h->fetches[k].plan_issued) && (!h->fetches[k].grid_dst || h->fetches[k].grid_issued)) k++;
+    while (k < h->fetches.size() && ((!h->fetches[k].plan_dst && !h->fetches[k].res_dst && !h->fetches[k].show_dst) || h->fetches[k].plan_issued) &&
+           (!h->fetches[k].grid_dst || h->fetches[k].grid_issued)) k++;
     h->fetches.erase(h->fetches.begin(), h->fetches.begin() + (long)k);
     return PP_OK;
 }
@@ -480,6 +486,8 @@ int pp_destroy(pp_handle h)
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     if (h->stream_s) (void)hipStreamSynchronize(h->stream_s);
+    if (h->stream_dg == h->stream_dp) h->stream_dg = nullptr;
+    if (h->stream_dp == h->stream_up) h->stream_dp = nullptr;
     for (hipStream_t st : { h->stream_up, h->stream_dp, h->stream_dg }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (int q = 0; q < kObs; q++) if (h->d_obs_now[q]) (void)hipFree(h->d_obs_now[q]);
     for (int q = 0; q < kIn; q++) {
@@ -1030,9 +1038,11 @@ static int ensure_streaming(pp_handle h)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     // the upload carries two small kernels (map views, slice check) that the next front chain waits for: top priority
+    int io_streams = 3;
+    if (const char* e = std::getenv("DMPP_IO_STREAMS")) io_streams = std::atoi(e);       // measurement knob: 1 = one stream for upload and both downloads, 2 = one for the downloads
     if (!h->stream_up) HIP_TRY(hipStreamCreateWithPriority(&h->stream_up, hipStreamNonBlocking, prio_greatest));
-    if (!h->stream_dp) HIP_TRY(hipStreamCreateWithPriority(&h->stream_dp, hipStreamNonBlocking, prio_least));
-    if (!h->stream_dg) HIP_TRY(hipStreamCreateWithPriority(&h->stream_dg, hipStreamNonBlocking, prio_least));
+    if (!h->stream_dp) { if (io_streams <= 1) h->stream_dp = h->stream_up; else HIP_TRY(hipStreamCreateWithPriority(&h->stream_dp, hipStreamNonBlocking, prio_least)); }
+    if (!h->stream_dg) { if (io_streams <= 2) h->stream_dg = h->stream_dp; else HIP_TRY(hipStreamCreateWithPriority(&h->stream_dg, hipStreamNonBlocking, prio_least)); }
     for (int q = 0; q < kPlan; q++) if (!h->ev_fetched_plan[q]) HIP_TRY(hipEventCreateWithFlags(&h->ev_fetched_plan[q], hipEventDisableTiming));
     for (int q = 0; q < kGout; q++) if (!h->ev_fetched_grid[q]) HIP_TRY(hipEventCreateWithFlags(&h->ev_fetched_grid[q], hipEventDisableTiming));
     for (int q = 0; q < kDone; q++) {
@@ -1105,10 +1115,10 @@ int pp_update_async(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint*
     return PP_OK;
 }
 
-int pp_fetch_async(pp_handle h, PlanOut* plan, GridOut* grid, long long* tick_id)
+static int fetch_async(pp_handle h, PlanOut* plan, PlanningOut* result, PlanningStatus* show, GridOut* grid, long long* tick_id)
 {
     if (!h) return fail(PP_ERR_ARG, "null handle");
-    if (!plan && !grid) return fail(PP_ERR_ARG, "nothing to fetch");
+    if (!plan && !grid && !result && !show) return fail(PP_ERR_ARG, "nothing to fetch");
     if (h->tick_seq == 0 || h->n_scenes <= 0) return fail(PP_ERR_STATE, "pp_fetch_async: no tick has been enqueued");
     if (grid && !h->cfg.grid_stage) return fail(PP_ERR_STATE, "pp_fetch_async: the last tick ran without the grid stage");
     HIP_TRY(hipSetDevice(h->device));
@@ -1126,14 +1136,15 @@ int pp_fetch_async(pp_handle h, PlanOut* plan, GridOut* grid, long long* tick_id
     }
     const TickRec& R = h->last_rec;
     if (h->done_tick[slot] != T) { h->done_tick[slot] = T; h->done_g_rec[slot] = false; h->done_p_rec[slot] = false; }
+    const bool want_plan = plan || result || show;
     PendingFetch f{};
     f.tick = T; f.slot = slot; f.n = (size_t)n; f.ev_front = R.ev_front; f.ev_tail = R.ev_tail;
-    if (plan) { f.plan_dst = plan; f.plan_src = h->d_plan; f.plan_set = h->plan_cur; h->done_p_rec[slot] = true; }
+    if (want_plan) { f.plan_dst = plan; f.res_dst = result; f.show_dst = show; f.plan_src = h->d_plan; f.plan_set = h->plan_cur; h->done_p_rec[slot] = true; }
     if (grid) { f.grid_dst = grid; f.grid_src = h->d_gout[h->gout_set]; f.grid_set = h->gout_set; h->done_g_rec[slot] = true; }
     // a second request for the same tick (PlanOut and GridOut asked for separately) joins the first
     bool joined = false;
     for (PendingFetch& g : h->fetches) if (g.tick == T) {
-        if (plan && !g.plan_dst) { g.plan_dst = f.plan_dst; g.plan_src = f.plan_src; g.plan_set = f.plan_set; g.plan_issued = false; joined = true; }
+        if (want_plan && !g.plan_dst && !g.res_dst && !g.show_dst) { g.plan_dst = f.plan_dst; g.res_dst = f.res_dst; g.show_dst = f.show_dst; g.plan_src = f.plan_src; g.plan_set = f.plan_set; g.plan_issued = false; joined = true; }
         if (grid && !g.grid_dst) { g.grid_dst = f.grid_dst; g.grid_src = f.grid_src; g.grid_set = f.grid_set; g.grid_issued = false; joined = true; }
     }
     if (!joined) h->fetches.push_back(f);
@@ -1141,6 +1152,10 @@ int pp_fetch_async(pp_handle h, PlanOut* plan, GridOut* grid, long long* tick_id
     if (tick_id) *tick_id = T;
     return PP_OK;
 }
+
+int pp_fetch_async(pp_handle h, PlanOut* plan, GridOut* grid, long long* tick_id) { return fetch_async(h, plan, nullptr, nullptr, grid, tick_id); }
+int pp_fetch_published_async(pp_handle h, PlanningOut* result, PlanningStatus* show, GridOut* grid, long long* tick_id)
+{ return fetch_async(h, nullptr, result, show, grid, tick_id); }
 
 long long pp_tick_id(pp_handle h) { return h ? h->tick_seq : -1; }
 

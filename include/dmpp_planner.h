@@ -154,6 +154,10 @@ int  pp_update_async(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint
  * for pp_wait_tick.  The device copies are overwritten 12 ticks later, which those ticks order
  * themselves after - the destination buffers are the caller's to rotate. */
 int  pp_fetch_async(pp_handle h, PlanOut* plan, GridOut* grid, long long* tick_id);
+/* The same for only what the reference publishes on every tick - PlanningOut (SetUdpSendCtrl, Planning.cpp:214) and
+ * PlanningStatus (SetPlanningStatus, Planning.cpp:186) of every scene, as two contiguous arrays (strided copies out of the
+ * PlanOut records: 3.3 of their 6.9 KB) - and / or GridOut.  Any of the three may be NULL. */
+int  pp_fetch_published_async(pp_handle h, PlanningOut* result, PlanningStatus* show, GridOut* grid, long long* tick_id);
 /* Host wait for the downloads of one tick (at most 32 ticks back).  *n_poisoned (may be NULL): scenes of that tick's update
  * that were poisoned; PP_ERR_ARG when there were any (the other scenes' results are valid), PP_OK otherwise. */
 int  pp_wait_tick(pp_handle h, long long tick_id, int* n_poisoned);

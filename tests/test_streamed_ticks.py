@@ -242,3 +242,36 @@ def test_streamed_egos_on_the_resident_map(dm, oracle):
     pl.sync()
     assert not compare(pl.get_state(), st_o, "state")
     pl.close()
+
+
+def test_streamed_published_records_only(dm, oracle):
+    """pp_fetch_published_async: what the reference publishes per tick - PlanningOut (SetUdpSendCtrl) and PlanningStatus
+    (SetPlanningStatus) - as two contiguous arrays, strided copies out of the PlanOut records."""
+    n, n_obs = 300, 16
+    cfg = dm.default_config(128)
+    cfg["force_replan"] = 1
+    sc = dm.gen_scenes(cfg, 9500, n, n_obs, junction_every=8)
+    pl = dm.Planner(cfg, device=0, max_scenes=n, max_obs_total=n * n_obs)
+    pl.set_scenes(sc, with_motion=False)
+    pl.set_state(sc["state"])
+    st_o = sc["state"].copy()
+    got, keep = [], []
+    for t in range(8):
+        move_ego(sc, 1)
+        a, b = dm.pinned_copy(sc["scene_in"]), dm.pinned_copy(sc["obs_pool"])
+        keep.append((a, b))
+        pl.update_async(a, b)
+        pl.tick()
+        res, show = dm.pinned_empty(n, dm.PlanningOut), dm.pinned_empty(n, dm.PlanningStatus)
+        grid = dm.pinned_empty(n, dm.GridOut) if t % 2 == 0 else None
+        tid = pl.fetch_published_async(res, show if t % 3 else None, grid)
+        plan_o, gout_o, _ = oracle.plan_tick_batch(cfg, dict(sc, mot_pool=None), st_o, n_threads=8)
+        got.append((tid, res, show if t % 3 else None, grid, plan_o, gout_o))
+    for t, (tid, res, show, grid, plan_o, gout_o) in enumerate(got):
+        assert pl.wait_tick(tid) == 0
+        assert not compare(res, plan_o["result"], "result"), t
+        if show is not None:
+            assert not compare(show, plan_o["show"], "show"), t
+        if grid is not None:
+            assert not compare(grid, gout_o, "grid"), t
+    pl.close()

@@ -40,6 +40,9 @@ for k in range(depth + 2):
         sc["obs_pool"]["x"] += rng.uniform(-0.3, 0.3, len(sc["obs_pool"]))
         sc["obs_pool"]["y"] += rng.uniform(-0.3, 0.3, len(sc["obs_pool"]))
     snaps.append((dm.pinned_copy(sc["scene_in"]), dm.pinned_copy(sc["obs_pool"])))
+WIRE = bool(os.environ.get("WIRE"))      # only the published records (PlanningOut + PlanningStatus) instead of the whole PlanOut
+ress = [dm.pinned_empty(n, dm.PlanningOut) for _ in range(depth)]
+shows = [dm.pinned_empty(n, dm.PlanningStatus) for _ in range(depth)]
 plans = [dm.pinned_empty(n, dm.PlanOut) for _ in range(depth)]
 grids = [dm.pinned_empty(n, dm.GridOut) for _ in range(depth)]
 
@@ -59,7 +62,10 @@ def run(k_steps, up, dp, dg, acc=None):
         pl.tick()
         a2 = time.perf_counter()
         if dp or dg:
-            ids.append(pl.fetch_async(plans[t % depth] if dp else None, grids[t % depth] if dg else None))
+            if WIRE:
+                ids.append(pl.fetch_published_async(ress[t % depth] if dp else None, shows[t % depth] if dp else None, grids[t % depth] if dg else None))
+            else:
+                ids.append(pl.fetch_async(plans[t % depth] if dp else None, grids[t % depth] if dg else None))
         a3 = time.perf_counter()
         if acc is not None:
             acc["update"] += a1 - a0
@@ -70,12 +76,12 @@ def run(k_steps, up, dp, dg, acc=None):
 
 
 CASES = (("plain ticks", (0, 0, 0)), ("upload only", (1, 0, 0)), ("PlanOut down only", (0, 1, 0)), ("GridOut down only", (0, 0, 1)),
-         ("both down", (0, 1, 1)), ("upload + PlanOut", (1, 1, 0)), ("all", (1, 1, 1)))
+         ("both down", (0, 1, 1)), ("upload + PlanOut", (1, 1, 0)), ("all", (1, 1, 1)), ("plain, streaming on", (0, 0, 0)))
 if os.environ.get("UP_PART"):        # upload only the egos / only the obstacles
     part = os.environ["UP_PART"]
     snaps = [((a if part == "in" else None), (b if part == "obs" else None)) for a, b in snaps]
 if os.environ.get("ONLY_ALL"):
-    CASES = (CASES[0], CASES[-1])
+    CASES = (CASES[0], CASES[-2], CASES[-1])
 for name, (up, dp, dg) in CASES:
     run(12, up, dp, dg)
     pl.sync()

@@ -141,6 +141,7 @@ struct DecShared {                                 // 19 KB: small enough to sit
     int n[6];
     int n_ref, do_sweep, n_cand;
     int rem_go, rem_flags;                        // remaining lane-change length tests (lane-change rule tree)
+    int rem_w[2][kBlock / 64]; double rem_s[2][kBlock / 64];   // ... their per-wave run ends and partial sums
 };
 
 
@@ -430,7 +431,7 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     const long long dbg_t0 = clock64();
     double* dbg_stamp = reinterpret_cast<double*>(dec_ref + (size_t)blockIdx.x * DMPP_MAX_REFPATH + 480);
 #endif
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const SceneIn& si = in[scene];
     SceneState& st = state[scene];
     PlanOut& po = plan[scene];
@@ -528,8 +529,7 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
         // Decision.cpp:1178-1187 (and :1212, 1316, 1344, 1459, 1477, 1506, 1523) walk the current lane from the ego point
         // while the next point's lanechg_attribute passes a predicate, summing segment lengths, and compare the sum with
         // 60 / 50 / 15 / 10 m.  As the compiler parses them the predicates are `attr == 1` (A), `attr & 1` (B) and
-        // constant false.  Partial sums of non-negative lengths never decrease, so "sum > t" is "some partial sum > t":
-        // segment lengths are produced 256 at a time by the block, thread 0 adds them in order and stops early.
+        // constant false.
         //   rem_flags bit0: A > 60, bit1: B > 10, bit2: B > 15, bit3: B > 50
         const bool run_tree = (LaneChg != 0) && c.lanechg_stage;
         if (run_tree) {
@@ -537,37 +537,88 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
             unsigned char* sa = sh.u.road.sa;
             const uint8_t* attr = attr_pool + si.lanes.cur_off;
             const int IdSum = si.lanes.cur_n;
-            int base = max(Id_Cur, 0);
-            double sumA = 0, sumB = 0; bool liveA = true, liveB = true; int flags = 0;
-            if (tid == 0) { sh.rem_go = 1; sh.rem_flags = 0; }
-            for (;;) {
-                __syncthreads();
-                if (!sh.rem_go) break;
-                const int i = base + tid;
-                if (i < IdSum - 1) {
-                    GlobalPoint2D a = { cur[i].x, cur[i].y }, b = { cur[i + 1].x, cur[i + 1].y };
-                    seg[tid] = CalcDistance(a, b); sa[tid] = attr[i + 1];
-                }
-                __syncthreads();
-                if (tid == 0) {
+            const int base0 = max(Id_Cur, 0);
+            // The flags only ask whether the IN-ORDER sum over a whole run of segments exceeds a threshold (the reference sums the run,
+            // then compares: Decision.cpp:1178-1190); the run's end comes from the attribute bytes (exact), and a sum taken in any other
+            // order differs from the in-order one by at most n u sum.  So the block reduces in parallel and decides every flag whose
+            // sum is farther than that bound from its threshold - all of them, in practice; should one be closer, thread 0 adds the
+            // run in order as the reference does.  A NaN length inside a run makes its sum NaN and every comparison false.
+            // (Thread 0 adding up to 256 lengths in order was 29 k of the kernel's 73 k cycles for a scene that may change lanes.)
+            bool ambiguous = false;
+            int flags = 0;
+            {
+                double sumA = 0, sumB = 0; bool liveA = true, liveB = true, nanA = false, nanB = false; int n_el = 0;
+                for (int base = base0; (liveA || liveB) && base < IdSum - 1; base += kBlock) {      // (uniform over the block)
                     const int cnt = min(kBlock, IdSum - 1 - base);
-                    for (int k = 0; k < cnt && (liveA || liveB); k++) {
-                        const unsigned a = sa[k]; const double d = seg[k];
-                        if (liveA) { if (a == 1) { sumA += d; if (sumA > 60) { flags |= 1; liveA = false; } } else liveA = false; }
-                        if (liveB) {
-                            if (a & 1) {
-                                sumB += d;
-                                if (sumB > 10) flags |= 2;
-                                if (sumB > 15) flags |= 4;
-                                if (sumB > 50) { flags |= 8; liveB = false; }
-                            } else liveB = false;
-                        }
+                    const bool in = tid < cnt;
+                    double d = 0; unsigned a = 0;
+                    if (in) {
+                        const int i = base + tid;
+                        GlobalPoint2D p0 = { cur[i].x, cur[i].y }, p1 = { cur[i + 1].x, cur[i + 1].y };
+                        d = CalcDistance(p0, p1); a = attr[i + 1];
                     }
-                    if (cnt < kBlock) { liveA = false; liveB = false; }
-                    sh.rem_go = (liveA || liveB) ? 1 : 0;
-                    sh.rem_flags = flags;
+                    const bool passA = in && a == 1, passB = in && (a & 1) != 0;
+                    const unsigned long long fa = wave_ballot(!passA), fb = wave_ballot(!passB);
+                    if (lane == 0) { sh.rem_w[0][wave] = fa ? __ffsll((long long)fa) - 1 : DMPP_WAVE; sh.rem_w[1][wave] = fb ? __ffsll((long long)fb) - 1 : DMPP_WAVE; }
+                    __syncthreads();
+                    int rA = 0, rB = 0;
+                    { bool go = true; for (int w = 0; w < kBlock / DMPP_WAVE; w++) if (go) { rA += sh.rem_w[0][w]; go = sh.rem_w[0][w] == DMPP_WAVE; } }
+                    { bool go = true; for (int w = 0; w < kBlock / DMPP_WAVE; w++) if (go) { rB += sh.rem_w[1][w]; go = sh.rem_w[1][w] == DMPP_WAVE; } }
+                    if (!liveA) rA = 0;
+                    if (!liveB) rB = 0;
+                    const bool isn = d != d;
+                    double pa = (tid < rA && !isn) ? d : 0.0, pb = (tid < rB && !isn) ? d : 0.0;
+                    const unsigned long long na = wave_ballot(tid < rA && isn), nb = wave_ballot(tid < rB && isn);
+#pragma unroll
+                    for (int sft = 32; sft >= 1; sft >>= 1) { pa += shfl_xor_f64(pa, sft); pb += shfl_xor_f64(pb, sft); }
+                    __syncthreads();
+                    if (lane == 0) { sh.rem_s[0][wave] = pa; sh.rem_s[1][wave] = pb; sh.rem_w[0][wave] = na ? 1 : 0; sh.rem_w[1][wave] = nb ? 1 : 0; }
+                    __syncthreads();
+                    for (int w = 0; w < kBlock / DMPP_WAVE; w++) {
+                        sumA += sh.rem_s[0][w]; sumB += sh.rem_s[1][w];
+                        nanA = nanA || sh.rem_w[0][w] != 0; nanB = nanB || sh.rem_w[1][w] != 0;
+                    }
+                    __syncthreads();
+                    n_el += cnt;
+                    if (rA < cnt || cnt < kBlock) liveA = false;          // the run (or the lane) ends in this block
+                    if (rB < cnt || cnt < kBlock) liveB = false;
                 }
-                base += kBlock;
+                const double epsA = (double)n_el * 2.3e-16 * sumA + 1e-300, epsB = (double)n_el * 2.3e-16 * sumB + 1e-300;
+                if (!nanA) { if (fabs(sumA - 60) <= epsA) ambiguous = true; else if (sumA > 60) flags |= 1; }
+                if (!nanB) {
+                    if (fabs(sumB - 10) <= epsB || fabs(sumB - 15) <= epsB || fabs(sumB - 50) <= epsB) ambiguous = true;
+                    if (sumB > 10) flags |= 2;
+                    if (sumB > 15) flags |= 4;
+                    if (sumB > 50) flags |= 8;
+                }
+            }
+            if (tid == 0) { sh.rem_go = ambiguous ? 1 : 0; sh.rem_flags = flags; }
+            if (__builtin_expect(ambiguous, 0)) {
+                // the in-order sums of both runs: segment lengths 256 at a time by the block, thread 0 adds them in order
+                int base = base0;
+                double sumA = 0, sumB = 0; bool liveA = true, liveB = true;
+                for (;;) {
+                    __syncthreads();
+                    if (!sh.rem_go) break;
+                    const int i = base + tid;
+                    if (i < IdSum - 1) {
+                        GlobalPoint2D a = { cur[i].x, cur[i].y }, b = { cur[i + 1].x, cur[i + 1].y };
+                        seg[tid] = CalcDistance(a, b); sa[tid] = attr[i + 1];
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        const int cnt = min(kBlock, IdSum - 1 - base);
+                        for (int k = 0; k < cnt && (liveA || liveB); k++) {
+                            const unsigned a = sa[k]; const double d = seg[k];
+                            if (liveA) { if (a == 1) sumA += d; else liveA = false; }
+                            if (liveB) { if (a & 1) sumB += d; else liveB = false; }
+                        }
+                        if (cnt < kBlock) { liveA = false; liveB = false; }
+                        sh.rem_go = (liveA || liveB) ? 1 : 0;
+                        sh.rem_flags = (sumA > 60 ? 1 : 0) | (sumB > 10 ? 2 : 0) | (sumB > 15 ? 4 : 0) | (sumB > 50 ? 8 : 0);
+                    }
+                    base += kBlock;
+                }
             }
         }
         FRONT_MARK(4)

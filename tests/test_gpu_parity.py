@@ -411,6 +411,61 @@ def test_lanechange_known_scenes(dm, oracle):
     assert changed >= 5            # the scenes do reach the "changing lanes" state
 
 
+def test_lanechange_remaining_length_fallbacks(dm, oracle):
+    """The remaining lane-change length flags are decided from a parallel sum unless that sum lies within its rounding bound of
+    a threshold or a length is NaN - then the in-order walk decides.  Exact thresholds (0.5 m spacing: 120 points = 60.0 m) and a
+    NaN lane point in the middle of the run, against the oracle's in-order loop; and a lane of 700 points (three blocks)."""
+    import lanechange_scenes as lcs
+    cfg = dm.default_config(128)
+    cfg["grid_stage"] = 0
+    pl = dm.Planner(cfg, device=0, max_scenes=1, max_obs_total=8, max_lane_pts_total=4096)
+    cases = []
+    for run in (119, 120, 121, 29, 30, 31, 99, 100, 101, 19, 20, 21):
+        for attr in (1, 3):
+            cases.append((dict(lane_num=2, map_attr=1, out_lanes=(2,) if attr == 1 else (1, 2), period=1600.0, obstacles=[(2, 10.0)], attr_ahead=attr, attr_run=run), None))
+    cases.append((dict(lane_num=2, map_attr=1, out_lanes=(2,), period=1600.0, obstacles=[(2, 10.0)], attr_run=250), 40))      # NaN 40 points ahead
+    cases.append((dict(lane_num=2, map_attr=1, out_lanes=(2,), period=1600.0, obstacles=[(2, 10.0)], attr_run=250), 150))
+    for k, (kw, nan_at) in enumerate(cases):
+        sc = lcs.make_scene(dm, cfg, **kw)
+        if nan_at is not None:
+            sc["lane_pool"]["x"][lcs.EGO_ID + nan_at] = np.nan
+        st_o = sc["state"].copy()
+        pl.set_state(sc["state"])
+        for t in range(4):
+            pl.set_scenes(sc)
+            pl.tick(sync=True)
+            plan_o, _, _ = oracle.plan_tick_batch(cfg, sc, st_o, want_grid=False)
+            bad = compare(pl.get_plan(), plan_o, "plan") + compare(pl.get_state(), st_o, "state")
+            assert not bad, f"case {k} {kw} nan {nan_at} tick {t}\n" + "\n".join(bad[:10])
+    # a long lane: the run crosses two block boundaries of the reduction (irregular spacing: no exact sums)
+    sc = lcs.make_scene(dm, cfg, lane_num=2, map_attr=1, out_lanes=(2,), period=1600.0, obstacles=[(2, 10.0)])
+    n_long = 700
+    rng = np.random.default_rng(3)
+    lane = np.zeros(n_long, dm.GlobalPoint3D)
+    lane["x"] = 100.0 + np.cumsum(rng.uniform(0.05, 0.12, n_long))
+    lane["y"] = sc["lane_pool"]["y"][0]
+    pool = np.concatenate([lane, sc["lane_pool"]])
+    attrs = np.concatenate([np.ones(n_long, np.uint8), sc["attr_pool"]])
+    attrs[600:n_long] = 0
+    sc2 = dict(sc, lane_pool=pool, attr_pool=attrs)
+    si = sc2["scene_in"] = sc["scene_in"].copy()
+    si["lanes"]["cur_off"], si["lanes"]["cur_n"] = 0, n_long
+    si["lanes"]["left_off"] += n_long
+    si["lanes"]["right_off"] += n_long
+    si["loc"]["id"][:] = 5
+    si["loc"]["globalpoint"]["x"] = lane["x"][5]
+    for j in range(len(sc2["obs_pool"])):
+        sc2["obs_pool"]["x"][j] = lane["x"][5] + 10.0
+    st_o = sc["state"].copy()
+    pl.set_state(sc["state"])
+    for t in range(4):
+        pl.set_scenes(sc2)
+        pl.tick(sync=True)
+        plan_o, _, _ = oracle.plan_tick_batch(cfg, sc2, st_o, want_grid=False)
+        bad = compare(pl.get_plan(), plan_o, "plan") + compare(pl.get_state(), st_o, "state")
+        assert not bad, f"long lane tick {t}\n" + "\n".join(bad[:10])
+
+
 def test_lanechange_generated_scenes(dm, oracle):
     """Generated scenes with mixed decision periods: 30 ticks, the ego advancing along its lane, every tick compared."""
     cfg = dm.default_config(128)

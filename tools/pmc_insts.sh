@@ -2,6 +2,8 @@
 # Runs ON THE GPU BOX: dynamic instruction counts per kernel (rocprofv3 PMC, its own pass, kernel-trace only).
 #   gpurun -- 'bash tools/pmc_insts.sh <tag> [bench args]'
 set -e
+# one rank only: under rocprofv3 bench.py must not start ranks itself (the profiler's preload has initialised the GPU: an exec from such a process takes the box down)
+for a in "$@"; do if [ "$prev" = "--gpus" ] && [ "$a" != "1" ]; then echo "refusing --gpus $a under rocprofv3 (profile one rank)" >&2; exit 2; fi; prev=$a; done
 TAG=${1:-x}
 export TMPDIR=/tmp
 R=$PWD

@@ -5,6 +5,8 @@
 #   gpurun --timeout 900 -- 'bash tools/profile.sh r1_c4 --grid 2048'        (extra bench.py arguments after the tag)
 # Results land in gpurun_out/prof_<tag>_*; copy the summaries into profiles/ with tools/profile_summary.py.
 set -e
+# one rank only: under rocprofv3 bench.py must not start ranks itself (the profiler's preload has initialised the GPU: an exec from such a process takes the box down)
+for a in "$@"; do if [ "$prev" = "--gpus" ] && [ "$a" != "1" ]; then echo "refusing --gpus $a under rocprofv3 (profile one rank)" >&2; exit 2; fi; prev=$a; done
 TAG=${1:-r1}
 export TMPDIR=/tmp
 R=$PWD

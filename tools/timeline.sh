@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: kernel timeline of a few ticks of the steady state (rocprofv3 --kernel-trace), as text.
 #   gpurun -- 'bash tools/timeline.sh <tag> [bench args]'
+for a in "$@"; do if [ "$prev" = "--gpus" ] && [ "$a" != "1" ]; then echo "refusing --gpus $a under rocprofv3 (profile one rank)" >&2; exit 2; fi; prev=$a; done
 TAG=${1:-x}
 export TMPDIR=/tmp
 R=$PWD

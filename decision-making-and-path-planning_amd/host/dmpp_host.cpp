@@ -117,7 +117,11 @@ int CShare::tick_io(bool decision_stage, const LocationOut& loc, const DecisionO
 {
     pp_handle h = handle(decision_stage, grid != nullptr);
     if (!h) return t_status.code ? t_status.code : PP_ERR_HIP;
-    if (obs.size() > (size_t)PP_IO_MAX_OBS) { pp_handle none = nullptr; (void)none; t_text = "more obstacles than PP_IO_MAX_OBS"; t_status.code = PP_ERR_CAPACITY; t_status.text = t_text.c_str(); return PP_ERR_CAPACITY; }
+    if (obs.size() > (size_t)PP_IO_MAX_OBS) {
+        t_text = "more obstacles than one PpSceneIo block carries (PP_IO_MAX_OBS)";
+        t_status.code = PP_ERR_CAPACITY; t_status.text = t_text.c_str();
+        return PP_ERR_CAPACITY;
+    }
     PpSceneIo& io = *m_io;
     io.in = m_in_template;
     io.in.loc = loc; io.in.dec = dec;

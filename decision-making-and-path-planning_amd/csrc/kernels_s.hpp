@@ -730,7 +730,8 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
     const int cap = SPILL ? c.bucket_cap : min(c.bucket_cap, kOpenCap);
     int sp_n = 0; uint32_t sp_min = 0xFFFFu;       // (SPILL) spilled entries (all live) and the smallest f / 2 among them
     SearchOut R; R.status = -1; R.n_exp = 0; R.n_push = 1; R.n_rounds = 0; R.path_cost = 0; R.path_len = 0; R.digest = 0;
-    int status = -1, n_exp = 0, n_push = 1, n_rounds = 0, path_cost = 0;
+    int status = -1, n_exp = 0, n_rounds = 0, path_cost = 0;
+    int my_pushes = 0;                                   // per lane (a counter nobody reads inside the loop need not be a scalar register)
     uint64_t digest = 0;
     bool hash_complete = true;                 // every closed cell is in the LDS hash (with its direction and run)
     int n_open = 1, live = 1, fmax = -1;
@@ -750,7 +751,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
     const int bj = is_dscan ? bq / 7 : 0, bk = is_dscan ? bq % 7 + 1 : 0;
     // cell-test lanes of the diagonal jumps: lanes 0..31 = (job, cell 1..8)
     const int aj = node, ak = (lane & 7) + 1;
-    long long guard = 16ll * N + 1024;                 // every iteration pops an entry; entries <= 8 per closed cell
+    int guard = 16 * N + 1024;                         // every iteration pops an entry; entries <= 8 per closed cell (N <= 2^24: fits)
     int steps = 0;
     while (status < 0) {
         if (__builtin_expect(--guard < 0, 0)) { status = DMPP_G_INTERNAL; break; }
@@ -1025,7 +1026,7 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
                 L.o_ent[slot] = (uint32_t)nx | ((uint32_t)ny << 12) | ((uint32_t)s << 24) | (nflags << 28);
                 L.o_run[slot] = (uint16_t)run;
             }
-            n_open += cnt; live += cnt; n_push += cnt;
+            n_open += cnt; live += cnt; my_pushes += push ? 1 : 0;
             wave_order();
         }
         DBG_MARK(4)
@@ -1173,6 +1174,10 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         }
     }
     DBG_MARK(6)
+    int n_push = my_pushes;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) n_push += __shfl_xor(n_push, sft, 64);
+    n_push += 1;                                         // the start node
     R.status = status; R.n_exp = n_exp; R.n_push = n_push; R.n_rounds = n_rounds; R.path_cost = path_cost; R.path_len = path_len; R.digest = digest;
     return R;
 #undef DBG_MARK

@@ -328,6 +328,19 @@ def test_cpp_host_classes_example():
     assert r.returncode == 0 and "example ok" in r.stdout
 
 
+def test_cpp_streamed_example():
+    """The streamed calls of the C-ABI from C++ (host/example_stream.cpp): 16 ticks of 320 scenes with a new snapshot each, six
+    in flight; the published records of the last tick must equal those of the synchronous calls on a second handle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "decision-making-and-path-planning_amd", "host", "example_stream")
+    assert os.path.exists(exe), "build it with make -C decision-making-and-path-planning_amd/host"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout[-1500:], r.stderr[-500:])
+    assert r.returncode == 0 and "example_stream ok" in r.stdout
+
+
 def test_grid_2048_bitmap_in_hbm(dm, oracle):
     """BASELINE configs[4] in small: 2048x2048 grid (64 line-mask bits per line: k_search_lds<2>; the sparse views need no more
     LDS than at 512 x 512 - the stored words follow the obstacles, not the grid)."""

@@ -38,7 +38,10 @@ struct EvPair { hipEvent_t a, b; int k; };
 
 // Buffers that a tick's search and scoring touch exist kBuf times, used round-robin ("parity"): up to kBuf searches of
 // consecutive ticks are in flight at once, each on its own stream, and scoring of tick t never holds up the search of t + 1.
-constexpr int kBuf = 3;
+#ifndef DMPP_KBUF
+#define DMPP_KBUF 3
+#endif
+constexpr int kBuf = DMPP_KBUF;
 // The obstacle snapshot exists 2 * kBuf times: the front chain of tick t writes its snapshot while the scoring pass of tick
 // t - kBuf still reads its own, so that chain need not wait for that pass (only for the search before it, see pp_plan_tick).
 constexpr int kObs = 2 * kBuf;
@@ -90,7 +93,8 @@ struct pp_planner {
     GlobalPoint2D* d_dec_ref = nullptr;
     // grid engine
     uint8_t* d_grid = nullptr; uint16_t* d_pinfo[kBuf] = {}; uint32_t* d_closed[kBuf] = {};
-    int32_t* d_order[kBuf] = {}; int32_t* d_path[kBuf] = {}; uint32_t* d_gbm[kBuf] = {};
+    int32_t* d_order[kBuf] = {}; int32_t* d_path[kObs] = {}; uint32_t* d_gbm[kBuf] = {};     // d_path, d_need: per snapshot set (the scoring pass of tick t reads them beside the search of tick t + kBuf)
+    int path_set = 0;                                  // the set of the last tick with the grid stage
     int32_t* d_perm[kBuf] = {}; int32_t* d_cost[kBuf] = {};
     uint2* d_ospill[kBuf] = {}; int spill_cap = 0; int32_t* d_retry[kBuf] = {};     // open-list spill areas (bucket_cap0 entries per scene; none when bucket_cap0 <= the LDS list)
     // Long searches (many obstacles, large grids) overlap their tails: the searches of odd ticks run on a second stream, and
@@ -101,7 +105,7 @@ struct pp_planner {
     // search: k_search_lds<kind> with `lds_budget` data words per view in LDS; scenes that need more go to k_search_gbm
     int search_kind = 0; int search_meta_bytes = 0; int lds_budget = 0, lds_budget_max = 0; bool lds_budget_fixed = false, search_force_gbm = false;
     int gbm_lds = 0; int search_slots = 512; size_t search_static_lds = 0;   // static LDS of k_search<kind>
-    int32_t* d_ovf[kBuf] = {}; int32_t* d_need[kBuf] = {}; int32_t* h_need = nullptr;   // h_need: pinned, [kBuf], written by k_score (-1: nothing yet)
+    int32_t* d_ovf[kBuf] = {}; int32_t* d_need[kObs] = {}; int32_t* h_need = nullptr;   // h_need: pinned, [kObs], written by k_score (-1: nothing yet)
     int need_seen = 0;
     int* d_gridbad = nullptr;
 
@@ -352,10 +356,11 @@ int setup_grid_launch(pp_planner* h)
             int r = dmalloc(&h->d_ovf[q], (size_t)h->caps.max_scenes); if (r) return r;
             HIP_TRY(hipMemsetAsync(h->d_ovf[q], 0, (size_t)h->caps.max_scenes * sizeof(int32_t), h->stream));
         }
-        if (!h->d_need[q]) { int r = dmalloc(&h->d_need[q], (size_t)2); if (r) return r; HIP_TRY(hipMemsetAsync(h->d_need[q], 0, 2 * sizeof(int32_t), h->stream)); }   // [0] LDS need of the search, [1] its retry count
         if (!h->d_retry[q]) { int r = dmalloc(&h->d_retry[q], (size_t)h->caps.max_scenes); if (r) return r; }
     }
-    if (!h->h_need) { HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_need), kBuf * sizeof(int32_t), hipHostMallocDefault)); for (int q = 0; q < kBuf; q++) h->h_need[q] = -1; }
+    for (int q = 0; q < kObs; q++)
+        if (!h->d_need[q]) { int r = dmalloc(&h->d_need[q], (size_t)2); if (r) return r; HIP_TRY(hipMemsetAsync(h->d_need[q], 0, 2 * sizeof(int32_t), h->stream)); }   // [0] LDS need of the search, [1] its retry count
+    if (!h->h_need) { HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_need), kObs * sizeof(int32_t), hipHostMallocDefault)); for (int q = 0; q < kObs; q++) h->h_need[q] = -1; }
     if (!h->d_gridbad) { int r = dmalloc(&h->d_gridbad, (size_t)2); if (r) return r; }
     if (sizeof(dmpp::ScoreShared<16>) > 48u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_score<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(dmpp::ScoreShared<16>));
@@ -423,7 +428,7 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     if (!h->stream_r)
     if (hipStreamCreateWithPriority(&h->stream_r, hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     if (!h->stream_s)
-    if (hipStreamCreateWithPriority(&h->stream_s, hipStreamNonBlocking, prio_least) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithPriority(&h->stream_s, hipStreamNonBlocking, (std::getenv("DMPP_SCORE_STREAM") && std::atoi(std::getenv("DMPP_SCORE_STREAM")) == 2) ? prio_greatest : prio_least) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_raster, hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
@@ -462,7 +467,7 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
             if ((r = dmalloc(&h->d_pinfo[q], ns * h->grid_cells))) return bail(r);
             if ((r = dmalloc(&h->d_closed[q], ns * (h->grid_cells / 32)))) return bail(r);
         }
-        for (int q = 0; q < kBuf; q++) if ((r = dmalloc(&h->d_path[q], ns * (size_t)cfg->max_path))) return bail(r);
+        for (int q = 0; q < kObs; q++) if ((r = dmalloc(&h->d_path[q], ns * (size_t)cfg->max_path))) return bail(r);
         for (int q = 0; q < kBuf; q++) if (caps->order_cap > 0 && (r = dmalloc(&h->d_order[q], ns * (size_t)caps->order_cap))) return bail(r);
         if (cfg->bucket_cap > DMPP_OPEN_CAP) {
             h->spill_cap = cfg->bucket_cap;
@@ -506,9 +511,10 @@ int pp_destroy(pp_handle h)
                      h->d_gridbad };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int q = 0; q < kBuf; q++)
-        for (void* b : { (void*)h->d_ospill[q], (void*)h->d_retry[q], (void*)h->d_pinfo[q], (void*)h->d_closed[q], (void*)h->d_order[q], (void*)h->d_path[q],
-                         (void*)h->d_gbm[q], (void*)h->d_perm[q], (void*)h->d_cost[q], (void*)h->d_ovf[q], (void*)h->d_need[q] })
+        for (void* b : { (void*)h->d_ospill[q], (void*)h->d_retry[q], (void*)h->d_pinfo[q], (void*)h->d_closed[q], (void*)h->d_order[q],
+                         (void*)h->d_gbm[q], (void*)h->d_perm[q], (void*)h->d_cost[q], (void*)h->d_ovf[q] })
             if (b) (void)hipFree(b);
+    for (int q = 0; q < kObs; q++) for (void* b : { (void*)h->d_path[q], (void*)h->d_need[q] }) if (b) (void)hipFree(b);
     for (int q = 0; q < kBuf; q++) if (h->ev_search[q]) (void)hipEventDestroy(h->ev_search[q]);
     for (int q = 0; q < kObs; q++) if (h->ev_score[q]) (void)hipEventDestroy(h->ev_score[q]);
     if (h->ev_raster) (void)hipEventDestroy(h->ev_raster);
@@ -740,7 +746,7 @@ int pp_plan_tick(pp_handle h)
         // is simply read here - whatever has landed; never waited for.
         if (!h->lds_budget_fixed) {
             int need = -1;
-            for (int q = 0; q < kBuf; q++) need = std::max(need, (int)reinterpret_cast<volatile int32_t*>(h->h_need)[q]);
+            for (int q = 0; q < kBuf; q++) need = std::max(need, (int)reinterpret_cast<volatile int32_t*>(h->h_need)[(h->obs_set + kObs - q) % kObs]);     // the last kBuf ticks' sets
             int want = h->lds_budget;
             if (need >= 0) {
                 h->need_seen = need;
@@ -768,14 +774,17 @@ int pp_plan_tick(pp_handle h)
     hipStream_t sf = piped ? h->stream_r : h->stream;                  // front chain
     hipStream_t ss = piped ? ((overlap && !h->score_own_stream) ? sm : h->stream_s) : h->stream; // score chain: behind its own search when the searches overlap
     hipStream_t sr = c.grid_stage ? h->stream_r : h->stream;           // Decision + Planning
-    // Buffers p were last used by tick t - kBuf (snapshot set po_b), snapshot set po by tick t - 2 kBuf.  The search waits for
-    // the scoring pass of tick t - kBuf; the front chain only for that tick's SEARCH (its launch order, and so that the front
-    // kernels run in the lull a finished search leaves) and for the scoring pass of tick t - 2 kBuf: it prepares the snapshot
-    // while the scoring pass of tick t - kBuf runs, and the search follows that pass without a hand-over.
+    // Buffers p were last used by tick t - kBuf (snapshot set po_b), snapshot set po - and with it the path cells and the LDS need
+    // of the search - by tick t - 2 kBuf.  The search follows the scoring pass of tick t - kBuf on its stream; the front chain waits
+    // for the scoring pass of tick t - 2 kBuf (it overwrites that pass's snapshot) and, see below, for the search of tick t - kBuf.
     const int po = (h->obs_set + 1) % kObs, po_b = (po + kBuf) % kObs;
-    if (h->score_recorded[po_b]) HIP_TRY(hipStreamWaitEvent(sm, h->ev_score[po_b], 0));
+    if (h->score_recorded[po_b] && ss == sm) HIP_TRY(hipStreamWaitEvent(sm, h->ev_score[po_b], 0));     // (own scoring stream: path cells and LDS need exist per snapshot set, the search of tick t does not wait for the scoring of t - kBuf)
     if (h->score_recorded[po]) HIP_TRY(hipStreamWaitEvent(sf, h->ev_score[po], 0));
-    if (h->search_recorded[p]) HIP_TRY(hipStreamWaitEvent(sf, h->ev_search[p], 0));
+    // The front chain does not wait for the search of tick t - kBuf: it runs ahead - up to kObs ticks, bounded by the snapshot
+    // sets - so its kernels no longer start together with the scoring pass that follows that search (+ 2 %), and the launch order,
+    // which needs that search's times, is computed on the search's own stream.  DMPP_FRONT_WAIT=1: the old hand-over (measurement knob).
+    static const bool front_wait = std::getenv("DMPP_FRONT_WAIT") && std::atoi(std::getenv("DMPP_FRONT_WAIT")) != 0;
+    if (h->search_recorded[p] && front_wait) HIP_TRY(hipStreamWaitEvent(sf, h->ev_search[p], 0));
     if (!overlap)                                                      // one search at a time (also after a switch of mode)
         for (int q = 0; q < kBuf; q++) if (q != p && h->search_recorded[q]) HIP_TRY(hipStreamWaitEvent(sm, h->ev_search[q], 0));
     if (h->front_recorded && sf == h->stream && h->front_unjoined) HIP_TRY(hipStreamWaitEvent(sf, h->ev_join, 0));   // Planning(t-1) -> snapshot(t) when not on the same stream
@@ -795,11 +804,10 @@ int pp_plan_tick(pp_handle h)
                            h->d_obs, h->have_motion ? h->d_mot : nullptr, obs_now);
     }
     if (sr != sf) { HIP_TRY(hipEventRecord(h->ev_fork, sf)); HIP_TRY(hipStreamWaitEvent(sr, h->ev_fork, 0)); }   // small batches: Decision + Planning beside the grid engine
-    // launch order of the search (heaviest scenes first) - pointless while every scene is resident at once.
-    // In the three-chain tick it is computed here, on the front chain, from the search of tick t-2 (certainly complete:
-    // this chain has waited for it), so that nothing stands between two consecutive searches on their stream.
+    // launch order of the search (heaviest scenes first) - pointless while every scene is resident at once.  Keyed by the times of
+    // the search kBuf ticks back, the one before it on its stream (one-stream tick: by the previous tick's).
     const bool order_scenes = c.grid_stage && n > h->search_slots;
-    const bool order_in_front = order_scenes && piped;
+    const bool order_in_front = order_scenes && piped && front_wait;
     if (order_in_front) hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sf, n, h->d_cost[p], h->d_perm[p]);
     if (sf != sm) HIP_TRY(hipEventRecord(h->ev_raster, sf));        // the search rasterises for itself: it only needs the obstacle snapshot (and its launch order)
     if (c.decision_stage) {
@@ -817,8 +825,8 @@ int pp_plan_tick(pp_handle h)
         if (sf != sm) HIP_TRY(hipStreamWaitEvent(sm, h->ev_raster, 0));
         if (h->streaming && h->fetched_grid_rec[gs]) HIP_TRY(wait_unless_done(sm, h->ev_fetched_grid[gs]));   // GridOut set still being downloaded (kGout grid ticks ago)
         const int32_t* perm = order_scenes ? h->d_perm[p] : nullptr;
-        if (perm && !order_in_front)          // one-stream tick with more scenes than search slots (DMPP_PIPELINE_MIN raised): keyed by the previous tick
-            hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[p_prev], h->d_perm[p]);
+        if (perm && !order_in_front)
+            hipLaunchKernelGGL(dmpp::k_order, dim3(1), dim3(dmpp::kOrderBlock), 0, sm, n, h->d_cost[overlap ? p : p_prev], h->d_perm[p]);
         {
             const int budget = h->search_force_gbm ? 0 : h->lds_budget;
             const bool wide = n <= kScoreWideMaxScenes;       // a few scenes: sixteen waves set each scene up (the latency-bound tick)
@@ -830,14 +838,14 @@ int pp_plan_tick(pp_handle h)
 #define DMPP_LAUNCH_SEARCH(K)                                                                                                                  \
                 case K:                                                                                                                        \
                     if (wide) hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWavesWide>), dim3(n), dim3(dmpp::kSearchSetupWavesWide * DMPP_WAVE), dyn, sm, c, n, h->caps.order_cap, budget, perm, \
-                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[gs], h->d_gbm[p], \
-                                           h->d_cost[p], h->d_ovf[p], h->d_need[p], h->d_ospill[p], h->spill_cap, h->d_retry[p], use_spill ? h->d_need[p] + 1 : nullptr); \
+                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[po], h->d_gout[gs], h->d_gbm[p], \
+                                           h->d_cost[p], h->d_ovf[p], h->d_need[po], h->d_ospill[p], h->spill_cap, h->d_retry[p], use_spill ? h->d_need[po] + 1 : nullptr); \
                     else hipLaunchKernelGGL((dmpp::k_search<K, dmpp::kSearchSetupWaves>), dim3(n), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget, perm,  \
-                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[gs], h->d_gbm[p], \
-                                           h->d_cost[p], h->d_ovf[p], h->d_need[p], h->d_ospill[p], h->spill_cap, h->d_retry[p], use_spill ? h->d_need[p] + 1 : nullptr); \
+                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[po], h->d_gout[gs], h->d_gbm[p], \
+                                           h->d_cost[p], h->d_ovf[p], h->d_need[po], h->d_ospill[p], h->spill_cap, h->d_retry[p], use_spill ? h->d_need[po] + 1 : nullptr); \
                     if (use_spill) hipLaunchKernelGGL((dmpp::k_search_spill<K>), dim3(std::min(n, 2)), dim3(dmpp::kSearchBlock), dyn, sm, c, n, h->caps.order_cap, budget,                       \
-                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[p], h->d_gout[gs], h->d_gbm[p],                              \
-                                           h->d_cost[p], h->d_ovf[p], h->d_need[p], h->d_ospill[p], h->spill_cap, h->d_retry[p], h->d_need[p] + 1);                           \
+                                           h->d_in, obs_now, h->d_closed[p], h->d_pinfo[p], h->d_order[p], h->d_path[po], h->d_gout[gs], h->d_gbm[p],                              \
+                                           h->d_cost[p], h->d_ovf[p], h->d_need[po], h->d_ospill[p], h->spill_cap, h->d_retry[p], h->d_need[po] + 1);                           \
                     break;
                 DMPP_LAUNCH_SEARCH(0) DMPP_LAUNCH_SEARCH(1) DMPP_LAUNCH_SEARCH(2)
 #undef DMPP_LAUNCH_SEARCH
@@ -848,19 +856,20 @@ int pp_plan_tick(pp_handle h)
         if (piped) { HIP_TRY(hipEventRecord(h->ev_search[p], sm)); HIP_TRY(hipStreamWaitEvent(ss, h->ev_search[p], 0)); }
         {
             Timed t(h, PP_K_SCORE, ss);
-            int32_t* need_host = (!h->lds_budget_fixed && !h->search_force_gbm) ? &h->h_need[p] : nullptr;
+            int32_t* need_host = (!h->lds_budget_fixed && !h->search_force_gbm) ? &h->h_need[po] : nullptr;
             if (n <= kScoreWideMaxScenes)     // few scenes: sixteen waves per scene (17 candidates in two rounds)
                 hipLaunchKernelGGL(dmpp::k_score<16>, dim3(n), dim3(16 * DMPP_WAVE), sizeof(dmpp::ScoreShared<16>), ss, c, n, h->d_in, obs_now,
-                                   h->d_path[p], h->d_gout[gs], h->d_need[p], need_host);
+                                   h->d_path[po], h->d_gout[gs], h->d_need[po], need_host);
             else
                 hipLaunchKernelGGL(dmpp::k_score<4>, dim3(n), dim3(4 * DMPP_WAVE), sizeof(dmpp::ScoreShared<4>), ss, c, n, h->d_in, obs_now,
-                                   h->d_path[p], h->d_gout[gs], h->d_need[p], need_host);
+                                   h->d_path[po], h->d_gout[gs], h->d_need[po], need_host);
         }
         h->score_recorded[po] = piped;
         if (piped) HIP_TRY(hipEventRecord(h->ev_score[po], ss));
         if (!piped && sr != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));   // one-stream mode: the tick is complete on the handle's stream
     }
     h->parity = p; h->obs_set = po; h->gout_set = gs; h->last_piped = piped;
+    if (c.grid_stage) h->path_set = po;
     h->tick_seq++;
     if (h->streaming) {          // what a later update of this tick's input set, and a download of its results, wait for
         TickRec rec = { h->tick_seq, h->in_cur, get_sync_event(h), c.grid_stage ? get_sync_event(h) : nullptr };
@@ -996,7 +1005,7 @@ int pp_get_path(pp_handle h, int scene, int32_t* path, int cap)
     if (!h || !path || !h->d_path[0]) return fail(PP_ERR_ARG, "no path buffer");
     if (scene < 0 || scene >= h->n_scenes) return fail(PP_ERR_ARG, "scene out of range");
     if (cap > h->cfg.max_path) cap = h->cfg.max_path;
-    return fetch(h, path, h->d_path[h->parity] + (size_t)scene * h->cfg.max_path, (size_t)cap * sizeof(int32_t));
+    return fetch(h, path, h->d_path[h->path_set] + (size_t)scene * h->cfg.max_path, (size_t)cap * sizeof(int32_t));
 }
 
 int pp_plan_tick_batch(pp_handle h, int n_scenes, const SceneIn* in, const ObPoint* obs_pool, const ObMotion* mot_pool, int n_obs_total,
@@ -1467,7 +1476,7 @@ void* pp_device_ptr(pp_handle h, int which, size_t* bytes)
     case PP_BUF_PLAN_OUT: p = h->d_plan; b = ns * sizeof(PlanOut); break;
     case PP_BUF_GRID_OUT: p = h->d_gout[h->gout_set]; b = ns * sizeof(GridOut); break;      // the buffers of the last tick
     case PP_BUF_GRID: p = nullptr; b = 0; break;      // no occupancy grid is kept after a tick (the search builds it in LDS): use pp_get_grid
-    case PP_BUF_PATH: p = h->d_path[h->parity]; b = ns * (size_t)h->max_path0 * 4; break;
+    case PP_BUF_PATH: p = h->d_path[h->path_set]; b = ns * (size_t)h->max_path0 * 4; break;
     case PP_BUF_LANE_ATTR: p = h->d_attr; b = (size_t)h->caps.max_lane_pts_total; break;
     case PP_BUF_ORDER: p = h->d_order[h->parity]; b = ns * (size_t)h->caps.order_cap * 4; break;
     default: break;

@@ -296,17 +296,6 @@ __device__ __forceinline__ bool exact_span(double ou, double org, double cell, d
     return a <= b;
 }
 
-// A superset of the exact run, without evaluating the predicate: the estimate widened by two cells on both sides (the line masks
-// built from it may flag a word that stays zero).  Empty only when the line is exactly empty.
-__device__ __forceinline__ bool rough_span(double ou, double org, double inv_cell, double dv2, double R2, int lo, int hi, int& a, int& b)
-{
-    if (dv2 > R2) return false;
-    const double half = (double)__builtin_sqrtf((float)(R2 - dv2));
-    a = max((int)floor((ou - half - org) * inv_cell) - 2, lo);
-    b = min((int)floor((ou + half - org) * inv_cell) + 2, hi);
-    return a <= b;
-}
-
 // bits [p0, p1] of a line as (word, mask) pieces
 template <class F>
 __device__ __forceinline__ void for_words(int p0, int p1, F&& f)
@@ -340,7 +329,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int tid, int* s_wave /* [S
 // line = y, positions x; column-major half: line = x, positions y).  All kSearchBlock threads.
 // A wave owns the obstacles wv, wv + 4, ...; it computes 64 footprints at once (one per lane: the divisions are paid once
 // per obstacle, not per line) and then walks them, lanes 0..31 on a footprint's rows and lanes 32..63 on its columns.
-template <int SW, bool EXACT = true, class Emit>
+template <int SW, class Emit>
 __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m, Emit&& emit)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -378,9 +367,57 @@ __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const Scen
             for (int l = l0 + l32; l <= l1; l += 32) {
                 const double dv = (org_v + ((double)l + 0.5) * cell) - ov;
                 int a, b;
-                const bool any = EXACT ? exact_span(ou, org_u, cell, inv_cell, dv * dv, R2, ic, lo, hi, a, b)
-                                       : rough_span(ou, org_u, inv_cell, dv * dv, R2, lo, hi, a, b);
+                const bool any = exact_span(ou, org_u, cell, inv_cell, dv * dv, R2, ic, lo, hi, a, b);
                 if (any) emit(colhalf, l, a, b);
+            }
+        }
+    }
+}
+
+// Pass 1 of build_sparse_views: a SUPERSET of every exact span, in single precision.  The coordinates are taken relative to
+// the grid's origin first (|rel| <= S = grid extent + R), so their rounding is <= 2^-24 S; the squared radius carries a margin
+// that covers what this does to R2 - dv^2 (<= 2 R * 2^-22 S + 2^-23 R2, taken four times over), so the half-chord is never
+// shorter than the exact one, and the two cells the run is widened by on both sides absorb the rounding of the division
+// (<= 2^-22 * grid width cells).  emit() as for_each_span.
+template <int SW, class Emit>
+__device__ __forceinline__ void for_each_rough_span(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m, Emit&& emit)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int W = c.grid_w, H = c.grid_h;
+    const bool colhalf = lane >= 32;
+    const int l32 = lane & 31;
+    const float cellf = (float)c.cell, inv_cellf = (float)(1.0 / c.cell);
+    const GlobalPoint2D origin = si.grid_origin;
+    const double extent = (double)max(W, H) * c.cell;
+    auto bcast_f = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+    for (int base = 0; base < m; base += SW * DMPP_WAVE) {
+        float rx = 0, ry = 0, r2m = -1.0f;
+        int ix0 = 0, ix1 = -1, iy0 = 0, iy1 = -1;
+        const int j = base + wv + SW * lane;
+        if (j < m) {
+            const Footprint f = footprint_of(c, origin, obs[j], W, H);
+            ix0 = f.ix0; ix1 = f.ix1; iy0 = f.iy0; iy1 = f.iy1;
+            const double R = sqrt(f.R2), S = extent + R;
+            rx = (float)(f.ox - origin.x); ry = (float)(f.oy - origin.y);
+            r2m = (float)((f.R2 + 4.0 * (R * S * 0x1p-21 + f.R2 * 0x1p-23)) * (1.0 + 0x1p-22));
+        }
+        const unsigned long long anym = wave_ballot(j < m && ix1 >= ix0 && iy1 >= iy0);
+        const int left = m - base - wv;
+        const int cnt = left <= 0 ? 0 : min(DMPP_WAVE, (left + SW - 1) / SW);
+        for (int q = 0; q < cnt; q++) {
+            if (!((anym >> q) & 1ull)) continue;
+            const float fx = bcast_f(rx, q), fy = bcast_f(ry, q), R2 = bcast_f(r2m, q);
+            const int jx0 = __builtin_amdgcn_readlane(ix0, q), jx1 = __builtin_amdgcn_readlane(ix1, q);
+            const int jy0 = __builtin_amdgcn_readlane(iy0, q), jy1 = __builtin_amdgcn_readlane(iy1, q);
+            const float ou = colhalf ? fy : fx, ov = colhalf ? fx : fy;
+            const int l0 = colhalf ? jx0 : jy0, l1 = colhalf ? jx1 : jy1, lo = colhalf ? jy0 : jx0, hi = colhalf ? jy1 : jx1;
+            for (int l = l0 + l32; l <= l1; l += 32) {
+                const float dv = ((float)l + 0.5f) * cellf - ov;
+                const float h2 = R2 - dv * dv;
+                if (h2 < 0.0f) continue;
+                const float half = __builtin_sqrtf(h2);
+                const int a = max((int)floorf((ou - half) * inv_cellf) - 2, lo), b = min((int)floorf((ou + half) * inv_cellf) + 2, hi);
+                if (a <= b) emit(colhalf, l, a, b);
             }
         }
     }
@@ -388,7 +425,7 @@ __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const Scen
 
 // Builds both sparse views of a scene from its obstacle list.  All kSearchBlock threads; returns the words the larger view
 // needs (> budget: nothing was filled, the views are unusable).
-//   pass 1: which words of which lines the footprints can touch (from the span estimates, widened: a superset);
+//   pass 1: which words of which lines the footprints can touch (single-precision span estimates, widened: a superset);
 //   offsets: exclusive prefix sum of the word counts over the lines;  pass 2: the exact spans, OR-ed into the words.
 template <int K, int SW>
 __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const SceneIn& si, const ObPoint* __restrict__ obs, int m,
@@ -405,7 +442,7 @@ __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const 
     for (int l = tid; l < W; l += (SW * DMPP_WAVE)) vc.clear_line(l);
     __syncthreads();
     mark(); mark();
-    for_each_span<SW, false>(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
+    for_each_rough_span<SW>(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
         const int wa = a >> 5, wb = b >> 5;
         const M bits = (M)((((M)2) << (wb - wa)) - (M)1) << wa;
         if (colhalf) vc.or_mask(l, bits); else vr.or_mask(l, bits);

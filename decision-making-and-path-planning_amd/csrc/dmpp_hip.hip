@@ -2,8 +2,8 @@
 //
 // One handle = one device and all device buffers.  Streams: the handle's stream (copies, stand-alone operators, the whole
 // tick of a small batch), kBuf search streams (stream_m[0] is the handle's stream: the searches of consecutive ticks run
-// side by side, each followed by its own scoring pass), the FRONT stream stream_r (obstacle snapshot, launch order,
-// Decision, Planning: highest priority), stream_s (scoring on its own stream: a measurement knob), and - once streamed
+// side by side, each preceded by its launch order and followed by its own scoring pass), the FRONT stream stream_r (obstacle
+// snapshot, Decision, Planning: highest priority, running ahead of the searches), stream_s (scoring on its own stream: a measurement knob), and - once streamed
 // ticks are in use (pp_update_async / pp_fetch_async) - one upload and two download streams.  pp_plan_tick describes the
 // launch order and the events between the chains; batches below pipeline_min scenes run on the handle's stream with only
 // Decision + Planning forked beside the grid engine.  pp_set_* / pp_get_* join the chains first (join_all) and wait on
@@ -718,12 +718,13 @@ int pp_plan_tick(pp_handle h)
     const PlannerConfig& c = h->cfg;
     if (c.decision_stage && c.lanechg_stage && !h->have_attr)
         return fail(PP_ERR_ARG, "cfg.lanechg_stage needs the lane attribute pool (pp_set_scenes lane_attr_pool)");
-    // One tick = three chains.  FRONT (stream_r): obstacle snapshot, (launch order), Decision, Planning - short kernels;
-    // SEARCH (the handle's stream): k_search_lds (+ the dense fallback for scenes it hands on), the long one; SCORE
-    // (stream_s): k_score.  The obstacle snapshot, the path cells and GridOut alternate between two buffers by tick
-    // parity, so the front of tick t+1 and the score of tick t both run beside the search:
-    //   front(t)  waits for search(t-2) and score(t-2) [both read the snapshot p];
-    //   search(t) waits for the snapshot of front(t) and for score(t-2) [path / GridOut p];  score(t) waits for search(t).
+    // One tick = two chains.  FRONT (stream_r, highest priority): obstacle snapshot, Decision, Planning - short kernels, serial
+    // from tick to tick through SceneState.  SEARCH (stream_m[t % kBuf]): (launch order,) k_search, k_search_spill, k_score - the
+    // long one; the searches of kBuf consecutive ticks run side by side on their own streams.
+    //   search(t) waits for the snapshot of front(t) [ev_raster] and follows score(t - kBuf) on its stream;
+    //   front(t)  waits for score(t - kObs), whose snapshot set it overwrites - so it may run up to kObs ticks ahead of the scoring.
+    // What a search and its scoring pass write exists kBuf times (closed sets, orders, ...), what the scoring pass reads beside
+    // a later search kObs times (snapshot, path cells, LDS need), GridOut kGout times.
     // Small batches and ticks without the grid stage stay on one stream (a cross-stream hand-over costs tens of
     // microseconds; only Decision + Planning run beside the grid engine there).
     // (a tick without the grid stage leaves the search buffers alone: pp_get_grid_out / pp_get_path keep returning the last search)

@@ -299,35 +299,34 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
     // a wave that scores several candidates (four waves per scene) leaves it out and runs ONE packed pass for all of them at the
     // end - lane 8 c + j takes point 192 + j of its c-th candidate - and then adds each term to the lane that would have added it
     // (lane j, after its three earlier terms: the order of the sums does not change).
+    // (The loops over a wave's candidates and over a candidate's passes are NOT unrolled: point_terms is ~1,000 instructions, and
+    // eighteen copies of it made this kernel 129 KB of code; rolled it is 36 KB and exactly as fast, alone and beside the searches.)
     auto whole_candidate = [&](int k, int n_pass, double& off, double& pen_acc, double& k2_acc, int& first_hit, GlobalPoint2D* tail) {
-        GlobalPoint2D P[4];
         off = 0;
         if (k < nl) {
             const Bezier bz = sh.bz[k];
             off = (double)(k - (nl - 1) / 2) * c.lattice_step;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                P[q].x = wb0[q] * bz.x0 + wb1[q] * bz.x1 + wb2[q] * bz.x2 + wb3[q] * bz.x3;
-                P[q].y = wb0[q] * bz.y0 + wb1[q] * bz.y1 + wb2[q] * bz.y2 + wb3[q] * bz.y3;
+                GlobalPoint2D P;
+                P.x = wb0[q] * bz.x0 + wb1[q] * bz.x1 + wb2[q] * bz.x2 + wb3[q] * bz.x3;
+                P.y = wb0[q] * bz.y0 + wb1[q] * bz.y1 + wb2[q] * bz.y2 + wb3[q] * bz.y3;
+                if (lane + 64 * q < DMPP_PATH_POINTS) cand[lane + 64 * q] = P;
             }
         } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) P[q] = mean_point(c, sh.pts, sh.cum, a + 1, min(lane + 64 * q, DMPP_PATH_POINTS - 1), DMPP_PATH_POINTS);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) if (lane + 64 * q < DMPP_PATH_POINTS) cand[lane + 64 * q] = P[q];
-        if (tail) {                                        // points 190 .. 199 for the packed pass
-            if (lane >= kTailFirst - 128 && lane < 64) tail[lane - (kTailFirst - 128)] = P[2];            // 190, 191 (lanes 62, 63 of pass 2)
-            if (lane < DMPP_PATH_POINTS - 192) tail[192 - kTailFirst + lane] = P[3];                      // 192 .. 199
+#pragma nounroll
+            for (int q = 0; q < 4; q++)
+                if (lane + 64 * q < DMPP_PATH_POINTS) cand[lane + 64 * q] = mean_point(c, sh.pts, sh.cum, a + 1, lane + 64 * q, DMPP_PATH_POINTS);
         }
         wave_sync();
+        if (tail && lane < DMPP_PATH_POINTS - kTailFirst) tail[lane] = cand[kTailFirst + lane];      // points 190 .. 199 for the packed pass
         pen_acc = 0; k2_acc = 0; first_hit = DMPP_PATH_POINTS;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
+#pragma nounroll
+        for (int q = 0; q < n_pass; q++) {
             const int i = lane + 64 * q;
-            if (q < n_pass && i < DMPP_PATH_POINTS) {
+            if (i < DMPP_PATH_POINTS) {
                 double pen, kk2; bool hit;
-                point_terms(cand, i, P[q], pen, kk2, hit);
+                point_terms(cand, i, cand[i], pen, kk2, hit);
                 pen_acc += pen; k2_acc += kk2;
                 if (hit && i < first_hit) first_hit = i;
             }
@@ -336,36 +335,40 @@ __device__ __forceinline__ void score_body(const PlannerConfig& c, const SceneIn
     };
     const int rounds = (n_whole - wave + NW - 1) / NW;                 // whole candidates of this wave
     const bool pack_tail = kPackTail<NW> && (n_whole + NW - 1) / NW >= 2 && (n_whole + NW - 1) / NW <= kTailRounds;       // (uniform over the block)
-    if (!pack_tail) {
-        for (int k = wave; k < n_whole; k += NW) {
-            double off, pen_acc, k2_acc; int first_hit;
-            whole_candidate(k, 4, off, pen_acc, k2_acc, first_hit, nullptr);
-            publish(k, off, pen_acc, k2_acc, first_hit);
-        }
-    } else {
+    {
         double accP[kTailRounds], accK[kTailRounds], accOff[kTailRounds]; int accH[kTailRounds];
 #pragma unroll
-        for (int ci = 0; ci < kTailRounds; ci++) {
-            accP[ci] = 0; accK[ci] = 0; accOff[ci] = 0; accH[ci] = DMPP_PATH_POINTS;
-            if (ci < rounds) whole_candidate(wave + ci * NW, 3, accOff[ci], accP[ci], accK[ci], accH[ci], &sh.tail[wave % kTailWaves<NW>][ci][0]);
-        }
-        {   // the packed pass: lane 8 c + j = point 192 + j of candidate c
-            const int cl = lane >> 3, i = 192 + (lane & 7);
-            double pen = 0, kk2 = 0; bool hit = false;
-            if (cl < rounds) {
-                const GlobalPoint2D* cnd = &sh.tail[wave % kTailWaves<NW>][cl][0] - kTailFirst;      // cnd[i] = point i, i = 190 .. 199
-                point_terms(cnd, i, cnd[i], pen, kk2, hit);
-            }
-            const int hv = hit ? i : DMPP_PATH_POINTS;
+        for (int t = 0; t < kTailRounds; t++) { accP[t] = 0; accK[t] = 0; accOff[t] = 0; accH[t] = DMPP_PATH_POINTS; }
+#pragma nounroll
+        for (int ci = 0; ci < rounds; ci++) {
+            const int k = wave + ci * NW;
+            double off, pen_acc, k2_acc; int first_hit;
+            whole_candidate(k, pack_tail ? 3 : 4, off, pen_acc, k2_acc, first_hit, pack_tail ? &sh.tail[wave % kTailWaves<NW>][ci][0] : nullptr);
+            if (!pack_tail) publish(k, off, pen_acc, k2_acc, first_hit);
+            else {
 #pragma unroll
-            for (int ci = 0; ci < kTailRounds; ci++) {
-                const double vp = shfl_f64(pen, 8 * ci + (lane & 7)), vk = shfl_f64(kk2, 8 * ci + (lane & 7));
-                const int vh = __shfl(hv, 8 * ci + (lane & 7), 64);
-                if (ci < rounds && lane < DMPP_PATH_POINTS - 192) { accP[ci] += vp; accK[ci] += vk; accH[ci] = min(accH[ci], vh); }
+                for (int t = 0; t < kTailRounds; t++) if (t == ci) { accP[t] = pen_acc; accK[t] = k2_acc; accOff[t] = off; accH[t] = first_hit; }
             }
         }
+        if (pack_tail) {
+            {   // the packed pass: lane 8 c + j = point 192 + j of candidate c
+                const int cl = lane >> 3, i = 192 + (lane & 7);
+                double pen = 0, kk2 = 0; bool hit = false;
+                if (cl < rounds) {
+                    const GlobalPoint2D* cnd = &sh.tail[wave % kTailWaves<NW>][cl][0] - kTailFirst;      // cnd[i] = point i, i = 190 .. 199
+                    point_terms(cnd, i, cnd[i], pen, kk2, hit);
+                }
+                const int hv = hit ? i : DMPP_PATH_POINTS;
 #pragma unroll
-        for (int ci = 0; ci < kTailRounds; ci++) if (ci < rounds) publish(wave + ci * NW, accOff[ci], accP[ci], accK[ci], accH[ci]);
+                for (int ci = 0; ci < kTailRounds; ci++) {
+                    const double vp = shfl_f64(pen, 8 * ci + (lane & 7)), vk = shfl_f64(kk2, 8 * ci + (lane & 7));
+                    const int vh = __shfl(hv, 8 * ci + (lane & 7), 64);
+                    if (ci < rounds && lane < DMPP_PATH_POINTS - 192) { accP[ci] += vp; accK[ci] += vk; accH[ci] = min(accH[ci], vh); }
+                }
+            }
+#pragma unroll
+            for (int ci = 0; ci < kTailRounds; ci++) if (ci < rounds) publish(wave + ci * NW, accOff[ci], accP[ci], accK[ci], accH[ci]);
+        }
     }
     if (n_whole < nc) {
         struct Part { double pen[DMPP_WAVE], k2[DMPP_WAVE]; int hit[DMPP_WAVE]; };

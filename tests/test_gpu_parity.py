@@ -641,6 +641,59 @@ def test_non_square_grids(dm, oracle, gw, gh):
     assert found >= (4 if gw > 32 else 0)
 
 
+@pytest.mark.parametrize("grid,cell,origin", [(512, 0.2, (0.0, 0.0)), (512, 0.05, (4.1e6, -6.3e5)), (256, 1.0, (-2.5e6, 3.0e6)),
+                                              (2048, 0.2, (5.0e5, 4.4e6)), (128, 0.01, (1.0e6, 1.0e6))])
+def test_rasteriser_adversarial_footprints(dm, oracle, grid, cell, origin):
+    """Footprints chosen against the span estimates of the rasteriser (pass 1 in single precision on coordinates relative to the
+    grid origin, pass 2 from a raw square root, both certified by the oracle's own predicate): radii from a fraction of a cell to
+    several grid widths, centres on cell centres and cell borders, discs that graze a line exactly (dv^2 == R^2), centres outside
+    the grid that reach in, origins at 1e6 metres, cells from 1 cm to 1 m.  The exported grid (built by the code the search uses)
+    must equal the oracle's, brute-force form included."""
+    cfg0 = dm.default_config(grid)
+    cfg = cfg0.copy()
+    cfg["cell"] = cell
+    cfg["inflate"] = 0.35 * cell                                  # footprints down to less than a cell
+    infl = float(cfg["inflate"][0])
+    ext = grid * cell
+    rng = np.random.default_rng(int(grid * 1000 + cell * 100))
+    discs = []
+    for k in range(10):                                           # grazing: the disc's edge exactly on a line of cell centres
+        r = float(rng.uniform(2.5, 12.0)) * cell
+        cy = (int(rng.integers(20, grid - 20)) + 0.5) * cell
+        discs.append((float(rng.uniform(0.1, 0.9)) * ext, cy + (r + infl) * (1 if k % 2 else -1), r))          # its centre line +- R
+        discs.append(((int(rng.integers(20, grid - 20)) + 0.5) * cell - (r + infl), float(rng.uniform(0.1, 0.9)) * ext, r))
+    for k in range(8):                                            # centres on cell centres / cell borders, tiny and sub-cell radii
+        ix, iy = int(rng.integers(4, grid - 4)), int(rng.integers(4, grid - 4))
+        discs.append(((ix + (0.5 if k % 2 else 0.0)) * cell, (iy + (0.5 if k % 4 < 2 else 0.0)) * cell, [0.0, 0.3 * cell, 0.5 * cell, 1.0 * cell][k % 4]))
+    discs += [(-0.3 * ext, 0.4 * ext, 0.32 * ext), (0.5 * ext, 1.2 * ext, 0.25 * ext), (1.05 * ext, 1.05 * ext, 0.1 * ext),
+              (0.7 * ext, 0.3 * ext, 0.08 * ext), (-5.0 * ext, 0.5 * ext, 4.9 * ext), (0.2 * ext, -1.0 * ext, 0.9 * ext)]      # large, outside, reaching in (or not)
+    discs += [(float(rng.uniform(0, 1)) * ext, float(rng.uniform(0, 1)) * ext, float(rng.uniform(0.2, 3.0)) * cell) for _ in range(12)]
+    m = len(discs)
+    sc = dm.gen_scenes(cfg0, 0, 1, m, junction_every=0)            # (the generator places its own obstacles for the default cell: all overwritten)
+    si = sc["scene_in"]
+    si["grid_origin"]["x"], si["grid_origin"]["y"] = origin
+    for j, (x, y, r) in enumerate(discs):
+        sc["obs_pool"][j]["x"], sc["obs_pool"][j]["y"], sc["obs_pool"][j]["radius"], sc["obs_pool"][j]["type"] = origin[0] + x, origin[1] + y, r, 0
+    sc["mot_pool"][:] = 0
+    si["loc"]["globalpoint"]["x"], si["loc"]["globalpoint"]["y"] = origin[0] + 0.05 * ext, origin[1] + 0.05 * ext
+    si["goal"]["x"], si["goal"]["y"] = origin[0] + 0.95 * ext, origin[1] + 0.95 * ext
+    pl = dm.Planner(cfg, max_scenes=1, max_obs_total=m)
+    pl.set_scenes(sc)
+    pl.set_state(sc["state"])
+    pl.tick(sync=True)
+    obs = sc["obs_pool"][:m]
+    grid_o = oracle.rasterise(cfg, origin, obs)
+    assert np.array_equal(grid_o, oracle.rasterise(cfg, origin, obs, brute=True))
+    grid_g = pl.get_grid(0)
+    assert grid_g.shape == grid_o.shape and 0 < int(grid_o.sum()) < grid_o.size
+    assert np.array_equal(grid_g, grid_o), f"{int((grid_g != grid_o).sum())} cells differ"
+    # and the search on it: same expansion count, same path
+    st = sc["state"].copy()
+    _, go, _, _, path_o = oracle.plan_tick_one(cfg, sc, 0, st, order_cap=0)
+    g = pl.get_grid_out()[0]
+    assert int(g["status"]) == int(go["status"]) and int(g["n_expanded"]) == int(go["n_expanded"]) and int(g["path_len"]) == int(go["path_len"])
+
+
 # ---- the bench workloads at their full size (BASELINE configs[1], [3], [4]) -----------------------------
 @pytest.mark.parametrize("grid,n_obs,dynamic,n_ticks", [(512, 64, 0, 4), (512, 256, 1, 30), (2048, 64, 0, 2)],
                          ids=["configs1", "configs3", "configs4"])

@@ -115,6 +115,23 @@ def pmc_traffic(kernel, tags):
     return None, None
 
 
+def pmc_instructions(path=os.path.join(ROOT, "profiles", "r3_pmc_insts.txt")):
+    """Vector / scalar instructions per launch of every kernel of the tick, from the committed rocprofv3 PMC pass (tools/pmc_insts.sh
+    on configs[1], 1024 scenes): {kernel: (SQ_INSTS_VALU, SQ_INSTS_SALU)}.  None when the file is missing."""
+    import ast
+    if not os.path.exists(path):
+        return None
+    out = {}
+    for ln in open(path):
+        if " dispatches " not in ln or "{" not in ln:
+            continue
+        name = ln.split(" dispatches ")[0].replace("void ", "").replace("dmpp::", "").split("<")[0].strip()
+        if name.startswith("k_") and name != "k_validate_scenes":       # (validation runs once per pp_set_scenes, not per tick)
+            d = ast.literal_eval(ln[ln.index("{"):].strip())
+            out[name] = (d.get("SQ_INSTS_VALU", 0), d.get("SQ_INSTS_SALU", 0))
+    return out or None
+
+
 def time_ticks(pl, steps, warmup, events=True):
     """W warm-up ticks, then K ticks between two full syncs; per-kernel averages from a second pass with events around
     every launch (the search kernel's from the timed pass).  Returns (seconds, {kernel: (ms_total, launches)})."""
@@ -540,6 +557,15 @@ def main():
             status_counts = np.sum([s["search_status_counts"] for s in multi["per_rank"]], axis=0)
         searched = int(status_counts.sum() - status_counts[dm.G_GOAL_BLOCKED])
         total = n * world
+        # how busy the vector units are over the whole tick: instructions of every kernel of the tick (committed PMC pass, configs[1]
+        # at 1024 scenes) x 4 cycles per wave64 instruction, over the SIMD-cycles of the tick time (1024 SIMDs, 2.4 GHz)
+        issue = None
+        pi = pmc_instructions()
+        if pi and n == 1024 and not args.dynamic and args.obstacles == 64 and args.grid == 512:
+            valu = sum(v for v, _ in pi.values()); salu = sum(sc_ for _, sc_ in pi.values())
+            issue = {"valu_insts_per_tick": valu, "salu_insts_per_tick": salu,
+                     "frac_of_valu_issue_slots": valu * 4.0 / (1024 * 2.4e9 * (dt / args.steps)),
+                     "source": "profiles/r3_pmc_insts.txt (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU, per launch of each kernel of the tick)"}
         line = {
             "metric": "planning ticks/sec (batched scenes), %dx%d grid" % (args.grid, args.grid),
             "value": total * args.steps / dt,
@@ -581,7 +607,9 @@ def main():
                          # what the kernel really moves through HBM, over its launch time (traffic is far below the algorithmic bytes: the
                          # grid is rasterised into LDS): the kernel is bound by the latency of its longest scene's chain of steps, not by HBM
                          "measured_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
-                         "limiter": "latency: one wave per scene, the launch ends with its slowest scene (dependent LDS round trips and ~1,350 instructions per step)",
+                         "limiter": "latency: one wave per scene, the launch ends with its slowest scene (dependent LDS round trips and ~1,350 instructions per step)"
+                                    + ("; the ticks in flight beside it take the share of the chip's vector issue slots given under `issue`" if issue else ""),
+                         "issue": issue,
                          # up to three launches of the search run side by side (consecutive ticks on three streams): what the chip
                          # sustains is the same bytes over the tick time; `achieved` stays the per-launch figure
                          "launches_in_flight": 3 if (n >= 256 and dom == "k_search") else 1,

@@ -118,7 +118,9 @@ struct pp_planner {
     int parity = 0;              // buffers of the last tick
     bool last_piped = false;     // the last tick ran as three chains on several streams (else it ended on the handle's stream)
     int obs_set = 0;             // obstacle snapshot of the last tick (d_obs_now[obs_set])
-    bool score_own_stream = false;   // env DMPP_SCORE_STREAM=1 (measurement knob): k_score on one stream of its own
+    bool score_own_stream = false;   // env DMPP_SCORE_STREAM=1 | 2 (measurement knob): k_score on one stream of its own, lowest | highest queue priority
+    bool score_stream_high = false;
+    bool front_wait = false;         // env DMPP_FRONT_WAIT=1 (measurement knob): the front chain waits for the search kBuf ticks back, as in rounds 1 - 2
     int n_cus = 256;
     int pipeline_min = 256;      // batches at least this large run the three chains on three streams (env DMPP_PIPELINE_MIN)
     bool r_on_main = false;      // the last tick ran Decision + Planning on the handle's stream (grid stage off)
@@ -424,11 +426,12 @@ int pp_create(const PlannerConfig* cfg, int device, const PlannerCaps* caps, pp_
     if (side_cus > 0 && hipExtStreamCreateWithCUMask(&h->stream_r, cu_words, cu_mask) != hipSuccess) { (void)hipGetLastError(); h->stream_r = nullptr; side_cus = 0; }
     if (side_cus > 0 && hipExtStreamCreateWithCUMask(&h->stream_s, cu_words, cu_mask) != hipSuccess) { (void)hipGetLastError(); h->stream_s = nullptr; }
     if (const char* e = std::getenv("DMPP_OVERLAP")) h->overlap_override = std::atoi(e);
-    if (const char* e = std::getenv("DMPP_SCORE_STREAM")) h->score_own_stream = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DMPP_SCORE_STREAM")) { h->score_own_stream = std::atoi(e) != 0; h->score_stream_high = std::atoi(e) == 2; }
+    if (const char* e = std::getenv("DMPP_FRONT_WAIT")) h->front_wait = std::atoi(e) != 0;
     if (!h->stream_r)
     if (hipStreamCreateWithPriority(&h->stream_r, hipStreamNonBlocking, prio_greatest) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     if (!h->stream_s)
-    if (hipStreamCreateWithPriority(&h->stream_s, hipStreamNonBlocking, (std::getenv("DMPP_SCORE_STREAM") && std::atoi(std::getenv("DMPP_SCORE_STREAM")) == 2) ? prio_greatest : prio_least) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithPriority(&h->stream_s, hipStreamNonBlocking, h->score_stream_high ? prio_greatest : prio_least) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipStreamCreate failed"));
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_raster, hipEventDisableTiming) != hipSuccess) return bail(fail(PP_ERR_HIP, "hipEventCreate failed"));
@@ -784,7 +787,7 @@ int pp_plan_tick(pp_handle h)
     // The front chain does not wait for the search of tick t - kBuf: it runs ahead - up to kObs ticks, bounded by the snapshot
     // sets - so its kernels no longer start together with the scoring pass that follows that search (+ 2 %), and the launch order,
     // which needs that search's times, is computed on the search's own stream.  DMPP_FRONT_WAIT=1: the old hand-over (measurement knob).
-    static const bool front_wait = std::getenv("DMPP_FRONT_WAIT") && std::atoi(std::getenv("DMPP_FRONT_WAIT")) != 0;
+    const bool front_wait = h->front_wait;
     if (h->search_recorded[p] && front_wait) HIP_TRY(hipStreamWaitEvent(sf, h->ev_search[p], 0));
     if (!overlap)                                                      // one search at a time (also after a switch of mode)
         for (int q = 0; q < kBuf; q++) if (q != p && h->search_recorded[q]) HIP_TRY(hipStreamWaitEvent(sm, h->ev_search[q], 0));

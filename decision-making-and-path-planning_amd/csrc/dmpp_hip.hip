@@ -312,7 +312,7 @@ int setup_grid_launch(pp_planner* h)
     // search: per-line metas of both sparse views + the budgeted data words in dynamic LDS (kernels_s.hpp)
     const int lw = (int)std::max((size_t)c.grid_w / 32, (size_t)c.grid_h / 32);
     h->search_kind = lw <= 16 ? 0 : (lw <= 32 ? 1 : 2);
-    const size_t per_line = h->search_kind == 0 ? 4 : (h->search_kind == 1 ? 8 : 12);
+    const size_t per_line = h->search_kind == 0 ? 4 : (h->search_kind == 1 ? 8 : 10);
     h->search_meta_bytes = (int)((((size_t)c.grid_w + c.grid_h) * per_line + 15) & ~(size_t)15);
     h->search_static_lds = h->search_kind == 2 ? sizeof(dmpp::SearchLds<dmpp::closed_log_of<2>()>) : sizeof(dmpp::SearchLds<dmpp::closed_log_of<0>()>);
     static_assert(dmpp::closed_log_of<0>() == dmpp::closed_log_of<1>(), "one static LDS size for the kinds 0 and 1");

@@ -91,13 +91,13 @@ template <class M> struct LineM { M mask; uint32_t off; };
 
 // Sparse view in LDS: only the words flagged in `mask` are stored, in word order, from data[off].
 //   K = 0: LW <= 16, one u32 per line (mask | off << 16);  K = 1: LW <= 32, uint2 {mask, off};
-//   K = 2: LW <= 64, u64 mask[] and u32 off[].
+//   K = 2: LW <= 64, u64 mask[] and u16 off[] (a view's data never exceeds the 160 KB of LDS: < 65536 words).
 #define DMPP_LDS __attribute__((address_space(3)))
 template <int K>
 struct SparseView {
     using M = std::conditional_t<K == 2, uint64_t, uint32_t>;
     // address_space(3): the compiler must know these are LDS (ds_read / ds_or), not generic pointers (flat_load)
-    DMPP_LDS uint32_t* data; DMPP_LDS unsigned char* meta; DMPP_LDS uint32_t* off2; int LW, NL;
+    DMPP_LDS uint32_t* data; DMPP_LDS unsigned char* meta; DMPP_LDS uint16_t* off2; int LW, NL;
 
     __device__ __forceinline__ LineM<M> line(int l) const
     {
@@ -126,7 +126,7 @@ struct SparseView {
     {
         if constexpr (K == 0) ((DMPP_LDS uint32_t*)meta)[l] = 0;
         else if constexpr (K == 1) { ((DMPP_LDS uint32_t*)meta)[2 * l] = 0; ((DMPP_LDS uint32_t*)meta)[2 * l + 1] = 0; }
-        else { ((DMPP_LDS uint64_t*)meta)[l] = 0; off2[l] = 0; }
+        else { ((DMPP_LDS uint64_t*)meta)[l] = 0; off2[l] = (uint16_t)0; }
     }
     __device__ __forceinline__ void or_mask(int l, M bits) const
     {
@@ -144,10 +144,10 @@ struct SparseView {
     {
         if constexpr (K == 0) ((DMPP_LDS uint32_t*)meta)[l] |= off << 16;
         else if constexpr (K == 1) ((DMPP_LDS uint32_t*)meta)[2 * l + 1] = off;
-        else off2[l] = off;
+        else off2[l] = (uint16_t)off;
     }
 };
-template <int K> __host__ __device__ constexpr int sparse_meta_bytes_per_line() { return K == 0 ? 4 : (K == 1 ? 8 : 12); }
+template <int K> __host__ __device__ constexpr int sparse_meta_bytes_per_line() { return K == 0 ? 4 : (K == 1 ? 8 : 10); }
 
 // Dense view: the bitmap of k_rasterise in HBM, one u64 mask per line in LDS (bit w = word w is non-zero).
 struct DenseView {
@@ -1283,8 +1283,8 @@ __device__ __forceinline__ void search_scene(const PlannerConfig& c, int scene, 
         unsigned used = 0;
         if constexpr (K == 2) {
             vr.meta = p; vc.meta = p + (unsigned)H * 8u;
-            vr.off2 = (DMPP_LDS uint32_t*)(p + (unsigned)(H + W) * 8u); vc.off2 = vr.off2 + H;
-            used = (unsigned)(H + W) * 12u;
+            vr.off2 = (DMPP_LDS uint16_t*)(p + (unsigned)(H + W) * 8u); vc.off2 = vr.off2 + H;
+            used = (unsigned)(H + W) * 10u;
         } else {
             constexpr unsigned mb = (unsigned)sparse_meta_bytes_per_line<K>();
             vr.meta = p; vc.meta = p + (unsigned)H * mb;
@@ -1426,8 +1426,8 @@ k_export_grid(PlannerConfig c, int scene, int budget, const SceneIn* __restrict_
         unsigned used = 0;
         if constexpr (K == 2) {
             vr.meta = p; vc.meta = p + (unsigned)H * 8u;
-            vr.off2 = (DMPP_LDS uint32_t*)(p + (unsigned)(H + W) * 8u); vc.off2 = vr.off2 + H;
-            used = (unsigned)(H + W) * 12u;
+            vr.off2 = (DMPP_LDS uint16_t*)(p + (unsigned)(H + W) * 8u); vc.off2 = vr.off2 + H;
+            used = (unsigned)(H + W) * 10u;
         } else {
             constexpr unsigned mb = (unsigned)sparse_meta_bytes_per_line<K>();
             vr.meta = p; vc.meta = p + (unsigned)H * mb;

@@ -755,7 +755,21 @@ int pp_plan_tick(pp_handle h)
             if (need >= 0) {
                 h->need_seen = need;
                 const int fit = std::min(h->lds_budget_max, (need + need / 8 + 64 + 63) / 64 * 64);
-                if (fit > h->lds_budget || fit < h->lds_budget - h->lds_budget / 4) want = fit;      // grow at once, shrink with hysteresis
+                // Workgroups per CU at a budget (1280 bytes per workgroup set aside for the allocation granule).  Where a smaller - still
+                // safe - slack over the need lets one more searching workgroup onto every CU, the largest budget that does is taken:
+                // 256 moving obstacles need ~4,650 words, 5,312 with the usual eighth on top = two workgroups of 55 KB per CU; three
+                // fit at <= 5,056 (configs[3]: 1.14 -> 1.23 M ticks/s).  A scene that outgrows the budget takes the dense form in HBM.
+                const size_t fixed_lds = h->search_static_lds + 64 + (size_t)h->search_meta_bytes + 1280;
+                auto wgs_at = [&](int b) { return (int)std::min<size_t>(8, (160u * 1024u) / (fixed_lds + 8 * (size_t)b)); };
+                int target = fit;
+                const int tight = std::min(h->lds_budget_max, (need + std::max(need / 32, 96) + 63) / 64 * 64);
+                if (tight < fit && wgs_at(tight) > wgs_at(fit)) {
+                    const size_t room = (160u * 1024u) / (size_t)wgs_at(tight);
+                    const int lim = room > fixed_lds ? (int)((room - fixed_lds) / 8 / 64 * 64) : 0;
+                    target = std::max(tight, std::min(lim, fit));
+                }
+                // grow at once, shrink with hysteresis - or when it buys a workgroup per CU
+                if (target > h->lds_budget || target < h->lds_budget - h->lds_budget / 4 || (h->lds_budget > 0 && wgs_at(target) > wgs_at(h->lds_budget))) want = target;
             }
             if (want <= 0) {
                 const long long per_scene = ((long long)h->n_obs_total + n - 1) / n;

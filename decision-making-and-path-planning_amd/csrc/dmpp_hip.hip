@@ -103,7 +103,7 @@ struct pp_planner {
     size_t grid_cells = 0;       // per scene, at creation
     int bucket_cap0 = 0, max_path0 = 0;
     // search: k_search_lds<kind> with `lds_budget` data words per view in LDS; scenes that need more go to k_search_gbm
-    int search_kind = 0; int search_meta_bytes = 0; int lds_budget = 0, lds_budget_max = 0; bool lds_budget_fixed = false, search_force_gbm = false;
+    int search_kind = 0; int search_meta_bytes = 0; int lds_budget = 0, lds_budget_max = 0; bool lds_budget_fixed = false, search_force_gbm = false, budget_from_need = false;
     int gbm_lds = 0; int search_slots = 512; size_t search_static_lds = 0;   // static LDS of k_search<kind>
     int32_t* d_ovf[kBuf] = {}; int32_t* d_need[kObs] = {}; int32_t* h_need = nullptr;   // h_need: pinned, [kObs], written by k_score (-1: nothing yet)
     int need_seen = 0;
@@ -362,7 +362,9 @@ int setup_grid_launch(pp_planner* h)
     }
     for (int q = 0; q < kObs; q++)
         if (!h->d_need[q]) { int r = dmalloc(&h->d_need[q], (size_t)2); if (r) return r; HIP_TRY(hipMemsetAsync(h->d_need[q], 0, 2 * sizeof(int32_t), h->stream)); }   // [0] LDS need of the search, [1] its retry count
-    if (!h->h_need) { HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_need), kObs * sizeof(int32_t), hipHostMallocDefault)); for (int q = 0; q < kObs; q++) h->h_need[q] = -1; }
+    if (!h->h_need) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_need), kObs * sizeof(int32_t), hipHostMallocDefault));
+    for (int q = 0; q < kObs; q++) h->h_need[q] = -1;       // (a new configuration: what earlier searches needed says nothing; no search is in flight here)
+    h->budget_from_need = false;
     if (!h->d_gridbad) { int r = dmalloc(&h->d_gridbad, (size_t)2); if (r) return r; }
     if (sizeof(dmpp::ScoreShared<16>) > 48u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dmpp::k_score<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(dmpp::ScoreShared<16>));
@@ -769,7 +771,11 @@ int pp_plan_tick(pp_handle h)
                     target = std::max(tight, std::min(lim, fit));
                 }
                 // grow at once, shrink with hysteresis - or when it buys a workgroup per CU
-                if (target > h->lds_budget || target < h->lds_budget - h->lds_budget / 4 || (h->lds_budget > 0 && wgs_at(target) > wgs_at(h->lds_budget))) want = target;
+                // (the first need that arrives replaces the first tick's guess outright: 64 obstacles were guessed at 2,048 words, need
+                // 1,635, and the hysteresis kept the guess - 28.2 KB per workgroup, 18.8 KB free beside five of them, 0.5 KB short of
+                // a k_decision workgroup; at 1,920 it fits: +1 % at 1024 scenes, +3 % at 4096)
+                if (!h->budget_from_need || target > h->lds_budget || target < h->lds_budget - h->lds_budget / 4 || (h->lds_budget > 0 && wgs_at(target) > wgs_at(h->lds_budget))) want = target;
+                h->budget_from_need = true;
             }
             if (want <= 0) {
                 const long long per_scene = ((long long)h->n_obs_total + n - 1) / n;

@@ -757,20 +757,24 @@ int pp_plan_tick(pp_handle h)
             if (need >= 0) {
                 h->need_seen = need;
                 const int fit = std::min(h->lds_budget_max, (need + need / 8 + 64 + 63) / 64 * 64);
-                // Workgroups per CU at a budget (1280 bytes per workgroup set aside for the allocation granule).  Where a smaller - still
-                // safe - slack over the need lets one more searching workgroup onto every CU, the largest budget that does is taken:
-                // 256 moving obstacles need ~4,650 words, 5,312 with the usual eighth on top = two workgroups of 55 KB per CU; three
-                // fit at <= 5,056 (configs[3]: 1.14 -> 1.23 M ticks/s).  A scene that outgrows the budget takes the dense form in HBM.
-                const size_t fixed_lds = h->search_static_lds + 64 + (size_t)h->search_meta_bytes + 1280;
-                auto wgs_at = [&](int b) { return (int)std::min<size_t>(8, (160u * 1024u) / (fixed_lds + 8 * (size_t)b)); };
+                // Workgroups per CU at a budget (the 160 KB of LDS are handed out in 128 granules of 1,280 bytes - measured: 54,000 bytes per
+                // workgroup are two per CU, 52,976 three, 26,864 six).
+                // When the scenes outnumber the workgroup slots and a smaller - still safe - slack over the need lets one more
+                // searching workgroup onto every CU, the largest budget that does is taken: 256 moving obstacles need ~4,650 words,
+                // 5,312 with the usual eighth on top = two workgroups of 55 KB per CU; three fit at <= 5,120 (configs[3]: 1.14 -> 1.23 M
+                // ticks/s); 4096 scenes of 64 obstacles: six of 26.9 KB instead of five of 27.9 (5.17 -> 5.30 M).  With a slot for every
+                // scene the eighth stays: the room it leaves on the CU is what the front kernels start in.  A scene that outgrows the
+                // budget takes the dense form in HBM.
+                const size_t fixed_lds = h->search_static_lds + 64 + (size_t)h->search_meta_bytes;
+                constexpr size_t kLdsGranule = 1280;
+                auto wgs_at = [&](int b) { return (int)std::min<size_t>(8, (160u * 1024u) / ((fixed_lds + 8 * (size_t)b + kLdsGranule - 1) / kLdsGranule * kLdsGranule)); };
                 int target = fit;
                 const int tight = std::min(h->lds_budget_max, (need + std::max(need / 32, 96) + 63) / 64 * 64);
-                if (tight < fit && wgs_at(tight) > wgs_at(fit)) {
-                    const size_t room = (160u * 1024u) / (size_t)wgs_at(tight);
+                if (tight < fit && wgs_at(tight) > wgs_at(fit) && n > wgs_at(fit) * std::max(1, h->n_cus)) {
+                    const size_t room = (160u * 1024u) / (size_t)wgs_at(tight) / kLdsGranule * kLdsGranule;
                     const int lim = room > fixed_lds ? (int)((room - fixed_lds) / 8 / 64 * 64) : 0;
                     target = std::max(tight, std::min(lim, fit));
                 }
-                // grow at once, shrink with hysteresis - or when it buys a workgroup per CU
                 // (the first need that arrives replaces the first tick's guess outright: 64 obstacles were guessed at 2,048 words, need
                 // 1,635, and the hysteresis kept the guess - 28.2 KB per workgroup, 18.8 KB free beside five of them, 0.5 KB short of
                 // a k_decision workgroup; at 1,920 it fits: +1 % at 1024 scenes, +3 % at 4096)

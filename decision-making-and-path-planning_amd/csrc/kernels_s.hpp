@@ -1364,8 +1364,13 @@ __device__ __forceinline__ void search_scene(const PlannerConfig& c, int scene, 
     }
 }
 
+#ifdef DMPP_SEARCH_VGPR          // experiment: cap the registers of the search kernel (occupancy while the set-up waves are resident)
+#define DMPP_SEARCH_ATTR __attribute__((amdgpu_waves_per_eu(DMPP_SEARCH_VGPR, DMPP_SEARCH_VGPR)))
+#else
+#define DMPP_SEARCH_ATTR
+#endif
 template <int K, int SW>
-__global__ void __launch_bounds__(SW * DMPP_WAVE)
+__global__ void __launch_bounds__(SW * DMPP_WAVE) DMPP_SEARCH_ATTR
 k_search(PlannerConfig c, int n_scenes, int order_cap, int budget, const int32_t* __restrict__ perm, const SceneIn* __restrict__ in,
          const ObPoint* __restrict__ obs_now, uint32_t* __restrict__ gclosed, uint16_t* __restrict__ pinfo, int32_t* __restrict__ orders,
          int32_t* __restrict__ paths, GridOut* __restrict__ gout, uint32_t* __restrict__ gbitmaps, int32_t* __restrict__ cost_out,

@@ -260,21 +260,37 @@ __device__ __forceinline__ Footprint footprint_of(const PlannerConfig& c, Global
 
 // Exact run [a, b] of indices i in [lo, hi] with  du(i)^2 + dv2 <= R2,  du(i) = (org + (i + 0.5) * cell) - ou.
 // `ic` = floor((ou - org) / cell), the index whose centre is nearest to ou (or next to it).  Returns false when empty.
-// The true indices form ONE run (see above), so an end is certified by two evaluations: true at the end, false just
-// outside.  The sqrt estimate passes that test nearly always; when it does not, the ends are walked to their place.
-__device__ __forceinline__ bool exact_span(double ou, double org, double cell, double inv_cell, double dv2, double R2, int ic,
+// The true indices form ONE run (see above).  Its ends come from a sqrt estimate of the half-chord, and are certified
+//   (1) by an error bound: x_a = (ou - half - org) / cell - 0.5 and x_b = (ou + half - org) / cell - 0.5 are where the run begins
+//       and ends on the real line; the predicate as evaluated in double precision can differ from the real-number one only
+//       for an index within `eps` of x_a or x_b, and the estimates are themselves within eps of the true values, with
+//         eps = (half * 2^-24  [raw hardware sqrt, ~2^-26 relative]  +  cq) / cell,
+//         cq  = 2^-47 (2 |org| + extent) + 2^-36 cell  [rounding of the coordinates, of du and of x itself; >= 16 times the bound]
+//               + 2^-30 (1 + R2)  [rounding of du^2 + dv2 moved to the boundary: 2^-53 R2 / half <= 2^-33 R for half >= 2^-20 R]
+//       so when neither x_a nor x_b lies within eps of an integer (and half >= 2^-20 R), a = ceil(x_a), b = floor(x_b) ARE the
+//       run (empty when a > b) - about ten instructions, no evaluation of the predicate (tests/test_oracle_properties.py
+//       ::test_span_ends_certified_by_margin replays this against the predicate; the adversarial rasteriser tests on the GPU);
+//   (2) otherwise (a few lines in a million) by the predicate itself: true at the end, false just outside; when that fails
+//       too, the ends are walked to their place.
+__device__ __forceinline__ bool exact_span(double ou, double org, double cell, double inv_cell, double dv2, double R2, double cq, int ic,
                                            int lo, int hi, int& a, int& b)
 {
     if (dv2 > R2) return false;                            // du*du >= 0: no index can satisfy the predicate
     auto pred = [&](int i) { const double du = (org + ((double)i + 0.5) * cell) - ou; return du * du + dv2 <= R2; };
-    // only an estimate (the predicate certifies the ends): the raw hardware square root (~2^-26 relative), without the refinement
-    // to a correctly rounded one (a single-precision estimate misses the certificate too often)
-    const double half = __builtin_amdgcn_sqrt(R2 - dv2);
-    a = clampi((int)ceil((ou - half - org) * inv_cell - 0.5), lo - 1, hi + 1);
-    b = clampi((int)floor((ou + half - org) * inv_cell - 0.5), lo - 1, hi + 1);
+    // only an estimate: the raw hardware square root (~2^-26 relative), without the refinement to a correctly rounded one
+    const double h2 = R2 - dv2;
+    const double half = __builtin_amdgcn_sqrt(h2);
+    const double xa = (ou - half - org) * inv_cell - 0.5, xb = (ou + half - org) * inv_cell - 0.5;
+    a = clampi((int)ceil(xa), lo - 1, hi + 1);
+    b = clampi((int)floor(xb), lo - 1, hi + 1);
+    {
+        const double lim = 0.5 - (half * 0x1p-24 + cq) * inv_cell;
+        const bool sure = (h2 >= R2 * 0x1p-40) & (fabs((xa - floor(xa)) - 0.5) < lim) & (fabs((xb - floor(xb)) - 0.5) < lim);
+        if (__builtin_expect(sure, 1)) { a = max(a, lo); b = min(b, hi); return a <= b; }
+    }
     const bool pa = pred(a), pa1 = pred(a - 1), pb = pred(b), pb1 = pred(b + 1);          // four independent evaluations, no short-circuit
     if (__builtin_expect(!((a <= b) & pa & !pa1 & pb & !pb1), 0)) {
-        // an empty run (the common reason: the footprint only grazes the line), or - rarely - an estimate one off.  A run that
+        // an empty run (the footprint only grazes the line), or an estimate one off.  A run that
         // is not empty contains the index nearest to ou: three evaluations certify emptiness; otherwise both ends are walked.
         const bool c0 = pred(ic), c1 = pred(ic - 1), c2 = pred(ic + 1);
         if (!(c0 | c1 | c2)) return false;
@@ -339,6 +355,8 @@ __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const Scen
     const double cell = c.cell, inv_cell = 1.0 / c.cell;
     const GlobalPoint2D origin = si.grid_origin;
     const double org_u = colhalf ? origin.y : origin.x, org_v = colhalf ? origin.x : origin.y;
+    // the scene's share of the error bound that certifies span ends (exact_span): coordinate rounding, with both axes' origins
+    const double cq_scene = 0x1p-47 * (2.0 * (fabs(origin.x) + fabs(origin.y)) + (double)max(W, H) * cell) + 0x1p-36 * cell;
     auto bcast_d = [](double v, int src) {
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
         return __hiloint2double(hi, lo);
@@ -364,10 +382,11 @@ __device__ __forceinline__ void for_each_span(const PlannerConfig& c, const Scen
             const int jcx = __builtin_amdgcn_readlane(icx, q), jcy = __builtin_amdgcn_readlane(icy, q);
             const double ou = colhalf ? fy : fx, ov = colhalf ? fx : fy;
             const int ic = colhalf ? jcy : jcx, l0 = colhalf ? ix0 : iy0, l1 = colhalf ? ix1 : iy1, lo = colhalf ? iy0 : ix0, hi = colhalf ? iy1 : ix1;
+            const double cq = cq_scene + 0x1p-30 * (1.0 + R2);
             for (int l = l0 + l32; l <= l1; l += 32) {
                 const double dv = (org_v + ((double)l + 0.5) * cell) - ov;
                 int a, b;
-                const bool any = exact_span(ou, org_u, cell, inv_cell, dv * dv, R2, ic, lo, hi, a, b);
+                const bool any = exact_span(ou, org_u, cell, inv_cell, dv * dv, R2, cq, ic, lo, hi, a, b);
                 if (any) emit(colhalf, l, a, b);
             }
         }

@@ -256,3 +256,59 @@ def test_curvature_fence_of_the_scoring_kernel_is_decided_by_the_oracle_chain():
     kernel = np.where(band, chain, fast)
     assert np.allclose(kernel, chain, rtol=1e-7, atol=0)         # (outside the band: the squared form, to rounding - ~1e-9 for the
                                                                  # near-equal sides of a resampled path, more for sides 1 : 60 as drawn here)
+
+
+def test_span_ends_certified_by_margin():
+    """The rasteriser inside k_search (csrc/kernels_s.hpp `exact_span`) takes a = ceil(x_a), b = floor(x_b) as the run of a line
+    without evaluating the predicate when neither estimate lies within `eps` of an integer.  This replays that rule in numpy -
+    the raw hardware square root modelled as the exact one with up to 2^-26 of relative error - against the predicate itself,
+    `du*du + dv2 <= R2` in double precision (the oracle's, dmpp_grid_oracle.c `orc_rasterise`): cells from 1 cm to 1 m, origins
+    up to 1e7 m, radii from 1 mm to 30 m, grazing lines, and boundaries placed 1e-12 ... 1e-4 cells from a cell centre.  Every
+    run the rule calls certain must be the predicate's run; what it does not call certain goes to the predicate on the GPU."""
+    rng = np.random.default_rng(20261005)
+
+    def pred(i, org, cell, ou, dv2, R2):
+        du = (org + (i.astype(np.float64) + 0.5) * cell) - ou
+        return du * du + dv2 <= R2
+
+    for adversarial in (False, True):
+        n = 400_000
+        cell = rng.choice([0.01, 0.05, 0.07, 0.1, 0.2, 0.25, 0.3, 0.5, 1.0], n)
+        W = rng.choice([32, 128, 512, 2048], n)
+        org = rng.choice([0.0, 1e3, -5e4, 3.3e5, 1e6, -1e6, 1e7], n) + rng.uniform(-100, 100, n)
+        extent = W * cell
+        R = np.exp(rng.uniform(np.log(1e-3), np.log(30.0), n))
+        R2 = R * R
+        ou = org + rng.uniform(-0.2, 1.2, n) * extent
+        graze = rng.random(n) < 0.2
+        dv = np.where(graze, R * (1 - np.exp(rng.uniform(np.log(1e-16), np.log(1e-2), n))), rng.uniform(0, 1, n) * R)
+        dv2 = dv * dv
+        keep = dv2 <= R2
+        h2 = R2 - dv2
+        if adversarial:
+            half0 = np.sqrt(np.maximum(h2, 0))
+            k = np.floor((ou - half0 - org) / cell)
+            d = np.exp(rng.uniform(np.log(1e-12), np.log(1e-4), n)) * rng.choice([-1, 1], n)
+            ou = np.where(rng.random(n) < 0.5, org + (k + 0.5 + d) * cell + half0, org + (k + 0.5 + d) * cell - half0)
+        half = np.sqrt(np.maximum(h2, 0)) * (1 + rng.uniform(-1, 1, n) * 2.0 ** -26)
+        inv = 1.0 / cell
+        xa = (ou - half - org) * inv - 0.5
+        xb = (ou + half - org) * inv - 0.5
+        # (the kernel's constant sums both axes' origins; one axis here: the smaller bound is the harder test)
+        cq = 2.0 ** -47 * (2 * np.abs(org) + extent) + 2.0 ** -36 * cell + 2.0 ** -30 * (1.0 + R2)
+        lim = 0.5 - (half * 2.0 ** -24 + cq) * inv
+        sure = keep & (h2 >= R2 * 2.0 ** -40) & (np.abs((xa - np.floor(xa)) - 0.5) < lim) & (np.abs((xb - np.floor(xb)) - 0.5) < lim)
+        idx = np.nonzero(sure)[0]
+        assert len(idx) > n // 5
+        ai = np.ceil(xa[idx]).astype(np.int64); bi = np.floor(xb[idx]).astype(np.int64)
+        o, c, u, d2, r2 = org[idx], cell[idx], ou[idx], dv2[idx], R2[idx]
+        nonempty = ai <= bi
+        for off in range(-3, 4):
+            inside_a = nonempty & (off >= 0) & (ai + off <= bi)
+            inside_b = nonempty & (off <= 0) & (bi + off >= ai)
+            assert np.array_equal(pred(ai + off, o, c, u, d2, r2), inside_a), (adversarial, off)
+            assert np.array_equal(pred(bi + off, o, c, u, d2, r2), inside_b), (adversarial, off)
+        # a run called empty: the predicate fails at the indices nearest to the obstacle too
+        ic = np.floor((u - o) / c).astype(np.int64)
+        for off in (-1, 0, 1):
+            assert not np.any(pred(ic + off, o, c, u, d2, r2) & ~nonempty), (adversarial, off)

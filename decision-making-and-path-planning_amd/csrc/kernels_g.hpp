@@ -58,6 +58,9 @@ k_score(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const ObP
         if (need_host) *need_host = v;
     }
     if (scene >= n_scenes) return;
+#ifdef DMPP_SCORE_PRIO                         // experiment knob: wave issue priority of the scoring pass (default 0)
+    __builtin_amdgcn_s_setprio(DMPP_SCORE_PRIO);
+#endif
     const SceneIn& si = in[scene];
     GridOut& go = gout[scene];
     score_body<NW>(c, si, obs_now + si.obs_off, si.obs_n, paths + (size_t)scene * c.max_path, go, go.status, go.path_len, sh);

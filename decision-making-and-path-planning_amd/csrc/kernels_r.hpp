@@ -14,6 +14,9 @@
 #pragma once
 #include "dev_geom.hpp"
 
+#ifndef DMPP_FRONT_PRIO
+#define DMPP_FRONT_PRIO 3          // wave issue priority of Decision / Planning (experiment knob: -DDMPP_FRONT_PRIO=2)
+#endif
 namespace dmpp {
 
 constexpr int kBlock = 256;
@@ -426,7 +429,7 @@ k_decision(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     DecShared& sh = *reinterpret_cast<DecShared*>(smem_raw);
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
-    __builtin_amdgcn_s_setprio(3);             // front chain: ahead of the searching waves on the same SIMD
+    __builtin_amdgcn_s_setprio(DMPP_FRONT_PRIO);             // front chain: ahead of the searching waves on the same SIMD
 #ifdef DMPP_DEBUG_SEARCH
     const long long dbg_t0 = clock64();
     double* dbg_stamp = reinterpret_cast<double*>(dec_ref + (size_t)blockIdx.x * DMPP_MAX_REFPATH + 480);
@@ -783,7 +786,7 @@ k_planning(PlannerConfig c, int n_scenes, const SceneIn* __restrict__ in, const 
     PlanShared& sh = *reinterpret_cast<PlanShared*>(smem_raw);
     const int scene = blockIdx.x;
     if (scene >= n_scenes) return;
-    __builtin_amdgcn_s_setprio(3);             // front chain: ahead of the searching waves on the same SIMD
+    __builtin_amdgcn_s_setprio(DMPP_FRONT_PRIO);             // front chain: ahead of the searching waves on the same SIMD
 #ifdef DMPP_DEBUG_SEARCH
     const long long dbg_t0 = clock64();
     double* dbg_stamp = const_cast<double*>(reinterpret_cast<const double*>(dec_ref + (size_t)blockIdx.x * DMPP_MAX_REFPATH + 490));

@@ -288,6 +288,9 @@ __device__ __forceinline__ bool exact_span(double ou, double org, double cell, d
         const bool sure = (h2 >= R2 * 0x1p-40) & (fabs((xa - floor(xa)) - 0.5) < lim) & (fabs((xb - floor(xb)) - 0.5) < lim);
         if (__builtin_expect(sure, 1)) { a = max(a, lo); b = min(b, hi); return a <= b; }
     }
+    // (the rare path: what it evaluates at ic, lo and hi does not depend on the line, and the compiler would hoist those thirty
+    // double-precision operations out of the loop over the lines - which runs once per obstacle - into every pass)
+    asm volatile("" : "+v"(ic), "+v"(lo), "+v"(hi));
     const bool pa = pred(a), pa1 = pred(a - 1), pb = pred(b), pb1 = pred(b + 1);          // four independent evaluations, no short-circuit
     if (__builtin_expect(!((a <= b) & pa & !pa1 & pb & !pb1), 0)) {
         // an empty run (the footprint only grazes the line), or an estimate one off.  A run that

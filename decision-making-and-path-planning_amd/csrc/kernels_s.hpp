@@ -464,11 +464,16 @@ __device__ __forceinline__ int build_sparse_views(const PlannerConfig& c, const 
     for (int l = tid; l < W; l += (SW * DMPP_WAVE)) vc.clear_line(l);
     __syncthreads();
     mark(); mark();
-    for_each_rough_span<SW>(c, si, obs, m, [&](bool colhalf, int l, int a, int b) {
+    auto mark_words = [&](bool colhalf, int l, int a, int b) {
         const int wa = a >> 5, wb = b >> 5;
         const M bits = (M)((((M)2) << (wb - wa)) - (M)1) << wa;
         if (colhalf) vc.or_mask(l, bits); else vr.or_mask(l, bits);
-    });
+    };
+#ifdef DMPP_EXACT_PASS1          // experiment: the exact spans in pass 1 too (fewer words allocated, more arithmetic)
+    for_each_span<SW>(c, si, obs, m, mark_words);
+#else
+    for_each_rough_span<SW>(c, si, obs, m, mark_words);
+#endif
     __syncthreads();
     mark();
     // ---- offsets: exclusive prefix sum of the word counts over the lines, per view ----

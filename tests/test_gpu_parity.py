@@ -668,6 +668,14 @@ def test_rasteriser_adversarial_footprints(dm, oracle, grid, cell, origin):
     discs += [(-0.3 * ext, 0.4 * ext, 0.32 * ext), (0.5 * ext, 1.2 * ext, 0.25 * ext), (1.05 * ext, 1.05 * ext, 0.1 * ext),
               (0.7 * ext, 0.3 * ext, 0.08 * ext), (-5.0 * ext, 0.5 * ext, 4.9 * ext), (0.2 * ext, -1.0 * ext, 0.9 * ext)]      # large, outside, reaching in (or not)
     discs += [(float(rng.uniform(0, 1)) * ext, float(rng.uniform(0, 1)) * ext, float(rng.uniform(0.2, 3.0)) * cell) for _ in range(12)]
+    # span ends ON cell centres (within the rounding of the float32 radius): centre on a cell centre and R = k cells - on the disc's
+    # own row and column, and (k = 5, 13: 3-4-5, 5-12-13) on the lines 3, 4, 5, 12 cells away - or centre on a cell border and
+    # R = k + 0.5 cells.  The error bound of exact_span cannot certify these ends: the predicate itself decides them, as in the oracle.
+    for k, half_cell in ((1, 0), (2, 0), (5, 0), (13, 0), (3, 1), (7, 1)):
+        if k + 2 >= grid // 4:
+            continue
+        ix, iy = int(rng.integers(k + 2, grid - k - 2)), int(rng.integers(k + 2, grid - k - 2))
+        discs.append(((ix + (0.0 if half_cell else 0.5)) * cell, (iy + (0.0 if half_cell else 0.5)) * cell, (k + 0.5 * half_cell) * cell - infl))
     m = len(discs)
     sc = dm.gen_scenes(cfg0, 0, 1, m, junction_every=0)            # (the generator places its own obstacles for the default cell: all overwritten)
     si = sc["scene_in"]

@@ -23,6 +23,10 @@
 #include <type_traits>
 #include "dev_geom.hpp"
 
+#ifndef DMPP_PRIO_T2
+#define DMPP_PRIO_T2 12         // steps after which a searching wave raises its issue priority to 2 ...
+#define DMPP_PRIO_T3 36         // ... and to 3 (experiment knobs)
+#endif
 namespace dmpp {
 
 __device__ __forceinline__ uint64_t mix64(uint64_t v)
@@ -821,8 +825,8 @@ __device__ __forceinline__ SearchOut search_core(const PlannerConfig& c, LDS& L,
         if (__builtin_expect(--guard < 0, 0)) { status = DMPP_G_INTERNAL; break; }
         // The kernel ends with its longest search, and several searching waves share a SIMD: a search that has already run
         // long issues ahead of the fresh ones (and of the set-up waves, which run at the lowest priority)
-        if (steps == 12) __builtin_amdgcn_s_setprio(2);
-        if (steps == 36) __builtin_amdgcn_s_setprio(3);
+        if (steps == DMPP_PRIO_T2) __builtin_amdgcn_s_setprio(2);
+        if (steps == DMPP_PRIO_T3) __builtin_amdgcn_s_setprio(3);
         steps++;
 #ifdef DMPP_DEBUG_SEARCH
         dbg_c[0]++;
